@@ -1,0 +1,133 @@
+"""ctypes binding of libctseg_hip.so (the C ABI declared in include/ctseg_hip.h).
+
+There is NO fallback: if the shared library is missing or a call is rejected this raises.
+PyTorch is used only for device memory and streams; every pointer handed over is a raw
+``data_ptr()`` and the stream is ``torch.cuda.current_stream().cuda_stream``.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libctseg_hip.so")
+
+F32, BF16 = 0, 1
+MAX_TAPS, MAX_CLASSES = 27, 8
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+_EPC = {F32: 4, BF16: 8}
+_SZ = {F32: 4, BF16: 2}
+
+
+def torch_dtype(dt):
+    return _TORCH_DT[dt]
+
+
+def epc(dt):
+    """elements per 16-byte chunk"""
+    return _EPC[dt]
+
+
+def elsize(dt):
+    return _SZ[dt]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class ConvClass(C.Structure):
+    _fields_ = [("ntaps", C.c_int32), ("kpad", C.c_int32), ("w_off", C.c_int64),
+                ("ox", C.c_int32), ("oy", C.c_int32), ("oz", C.c_int32), ("taps", C.c_int32 * MAX_TAPS)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+                ("add", C.c_void_p), ("stats", C.c_void_p), ("dtype", C.c_int32),
+                ("N", C.c_int32), ("Xi", C.c_int32), ("Yi", C.c_int32), ("Zi", C.c_int32),
+                ("Xr", C.c_int32), ("Yr", C.c_int32), ("Zr", C.c_int32),
+                ("Xo", C.c_int32), ("Yo", C.c_int32), ("Zo", C.c_int32),
+                ("Cg", C.c_int32), ("Cn", C.c_int32), ("Cn_store", C.c_int32),
+                ("g_ld", C.c_int32), ("o_ld", C.c_int32), ("add_ld", C.c_int32),
+                ("sin", C.c_int32), ("sout", C.c_int32), ("out_f32", C.c_int32), ("add_f32", C.c_int32),
+                ("stats_ld", C.c_int32), ("stats_tiles", C.c_int32), ("stats_tile0", C.c_int32),
+                ("nclass", C.c_int32), ("cls", ConvClass * MAX_CLASSES)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("dy", C.c_void_p), ("ws", C.c_void_p), ("dtype", C.c_int32),
+                ("N", C.c_int32), ("Xi", C.c_int32), ("Yi", C.c_int32), ("Zi", C.c_int32),
+                ("Xr", C.c_int32), ("Yr", C.c_int32), ("Zr", C.c_int32),
+                ("Cg", C.c_int32), ("Cn", C.c_int32), ("g_ld", C.c_int32), ("d_ld", C.c_int32), ("sin", C.c_int32),
+                ("ntaps", C.c_int32), ("taps", C.c_int32 * MAX_TAPS), ("splits", C.c_int32),
+                ("kpad_w", C.c_int32), ("cn_pad", C.c_int32)]
+
+
+_i32, _i64, _f32, _f64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+_SIGS = {
+    "ctseg_abi_version": (C.c_int, []),
+    "ctseg_last_error": (C.c_char_p, []),
+    "ctseg_conv_tile_rows": (C.c_int, [_i32]),
+    "ctseg_conv_tile_cols": (C.c_int, [_i32]),
+    "ctseg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "ctseg_wgrad_tile_cols": (C.c_int, [_i32]),
+    "ctseg_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
+    "ctseg_conv_wgrad_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ctseg_gather_cast": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp]),
+    "ctseg_instnorm_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp]),
+    "ctseg_instnorm_prelu_fwd": (C.c_int, [_i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
+    "ctseg_instnorm_prelu_bwd_reduce": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
+    "ctseg_instnorm_prelu_bwd_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _vp]),
+    "ctseg_instnorm_prelu_bwd_apply": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
+    "ctseg_colsum": (C.c_int, [_i32, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp]),
+    "ctseg_squash_masks": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "ctseg_seg_loss": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "ctseg_dice_counts": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    "ctseg_reduce_partials_f64": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "ctseg_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "ctseg_cast": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp]),
+    "ctseg_nc_to_cl": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
+    "ctseg_cl_to_nc": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
+}
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or `make -C ct-image-segmentation_amd`). There is no CPU/eager fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.ctseg_abi_version() != 1:
+            raise NativeError("libctseg_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NativeError(f"{what} failed ({rc}): {lib().ctseg_last_error().decode()}")
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args, stream_ptr()), name)
+
+
+def ptr(t, byte_offset=0):
+    return None if t is None else t.data_ptr() + byte_offset
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise NativeError(f"{what}: tensor is on {t.device}; the MI355X path needs a ROCm device tensor "
+                          "(there is no CPU fallback in the product path)")

@@ -1,0 +1,100 @@
+"""Data-parallel training: one process per GPU, RCCL all-reduce of the flat gradient buffer over xGMI.
+
+The reference has no distributed code of its own; multi-GPU is Lightning's DDP (gradient MEAN over
+ranks, bucketed NCCL all-reduce overlapped with backward) reached through Trainer flags
+(capstone/volumetric/base_trainer.py:196,217).  Here the whole gradient is one flat fp32 buffer laid
+out in gradient-readiness order, so the exchange is two collectives per step, not one per tensor:
+chunk 1 (decoder + bottleneck, ~76 % of the bytes) is launched as soon as the bottleneck's weight
+gradient retires and overlaps the encoder backward; chunk 2 (encoder) goes after the stem.  The 1/world
+factor is folded into the Adam kernel's ``grad_scale`` (no extra pass).  Samples are independent
+(InstanceNorm is per sample), so there is no other data-path collective.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as set by ``python -m torch.distributed.run``."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 0, 1
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def split_points(ready_marks, sizes, n_total, first_fraction=0.6):
+    """ready_marks: [(program index, [flat offsets that became final])], sizes: {offset: numel}.
+    Returns [(program index, end offset)] — after ``program index`` ops of backward the flat gradient is
+    final on [0, end).  Picks the earliest mark whose ready prefix covers ``first_fraction`` of the buffer."""
+    done, prefix, out = set(), 0, []
+    order = sorted(sizes)
+    pos = 0
+    for idx, offs in ready_marks:
+        done.update(offs)
+        while pos < len(order) and order[pos] in done:
+            prefix = order[pos] + sizes[order[pos]]
+            pos += 1
+        if not out and prefix >= first_fraction * n_total and prefix < n_total:
+            out.append((idx, prefix))
+    return out
+
+
+class GradAllReducer:
+    def __init__(self, flat_g, n, ready_marks=None, sizes=None, group=None):
+        self.flat_g, self.n, self.group = flat_g, n, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.points = split_points(ready_marks, sizes, n) if ready_marks else []
+        self.works, self.sent = [], 0
+
+    def _launch(self, lo, hi):
+        if hi > lo and self.world > 1:
+            self.works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def hooks(self, plan=None):
+        """{backward program index: callable} — fired by Plan.backward between ops"""
+        self.works, self.sent = [], 0
+        h = {}
+        for idx, end in self.points:
+            def fire(end=end):
+                self._launch(self.sent, end)
+                self.sent = end
+            h[idx] = fire
+        return h
+
+    def finish(self):
+        """all-reduce the rest, make the compute stream wait for every chunk; returns the Adam grad_scale"""
+        self._launch(self.sent, self.n)
+        self.sent = self.n
+        for w in self.works:
+            w.wait()
+        self.works = []
+        return 1.0 / self.world
+
+
+def broadcast_params(flat_p, group=None):
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_p, src=0, group=group)
+
+
+def attach(module, group=None):
+    """make a BaseUNet3D data-parallel: identical weights on every rank + overlapped gradient all-reduce."""
+    eng = module.unet.engine()
+    st = eng.store
+    assert st is not None, "run one forward (or engine.ensure(device)) before attach()"
+    broadcast_params(st.flat_p, group)
+    plan = eng.last_plan
+    sizes = {st.off(p): p.numel() for p in st.params}
+    module.reducer = GradAllReducer(st.flat_g, st.n, plan.ready_marks if plan is not None else None, sizes, group)
+    if plan is not None:
+        plan.packer.dirty = True
+    return module.reducer

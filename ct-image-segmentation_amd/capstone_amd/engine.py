@@ -1,0 +1,455 @@
+"""Host-side execution engine for the MI355X U-Net path.
+
+Walks the MONAI-shaped module tree (capstone_amd.models.unet) ONCE per (device, dtype, input
+shape) and records the forward and backward passes as flat programs of C-ABI calls
+(include/ctseg_hip.h) over pre-allocated channels-last buffers.  Running a step is then a plain
+loop over ``(cfunc, args)`` tuples on the current HIP stream: no autograd graph, no per-step
+allocation, no tracing compiler.
+
+What is fused where (see DESIGN.md for the byte accounting):
+  * the stride-2 residual conv and ``unit0`` conv of a down ResidualUnit share their input and
+    geometry -> ONE implicit GEMM with 2*C columns (and one fused dgrad / wgrad);
+  * InstanceNorm statistics come out of the conv epilogue; ``prelu(norm(y)) + residual`` is one
+    elementwise pass that writes straight into the skip-concat buffer (torch.cat is free);
+  * ConvTranspose3d runs as 8 output-parity classes in one launch, no zero insertion; its input
+    gradient is a stride-2 conv pass, the stride-2 conv's input gradient is the 8-class pass;
+  * every gradient lands in one flat fp32 buffer (all-reduce + Adam are single launches).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from ._native import BF16, F32
+
+
+def rup(a, b):
+    return (a + b - 1) // b * b
+
+
+class Act:
+    """Channels-last activation handle: tensor [N,X,Y,Z,ld], C valid channels starting at c0."""
+    __slots__ = ("t", "C", "c0", "dt")
+
+    def __init__(self, t, C, c0=0, dt=None):
+        self.t, self.C, self.c0 = t, C, c0
+        self.dt = dt if dt is not None else (F32 if t.dtype == torch.float32 else BF16)
+
+    @property
+    def dims(self):
+        return tuple(self.t.shape[:4])
+
+    @property
+    def ld(self):
+        return self.t.shape[4]
+
+    @property
+    def S(self):
+        s = self.t.shape
+        return s[1] * s[2] * s[3]
+
+    def ptr(self):
+        return self.t.data_ptr() + self.c0 * self.t.element_size()
+
+    def slice(self, c0, C):
+        return Act(self.t, C, self.c0 + c0, self.dt)
+
+    def valid(self):
+        """torch view of the valid channels, logical NC[XYZ] order"""
+        return self.t[..., self.c0:self.c0 + self.C].permute(0, 4, 1, 2, 3)
+
+
+def new_act(N, X, Y, Z, C, dt, device, ld=None, zero=True):
+    ld = ld if ld is not None else rup(C, nat.epc(dt))
+    f = torch.zeros if zero else torch.empty
+    return Act(f((N, X, Y, Z, ld), dtype=nat.torch_dtype(dt), device=device), C, 0, dt)
+
+
+# ------------------------------------------------------------------------------------------------
+# taps
+# ------------------------------------------------------------------------------------------------
+def _pack_off(dx, dy, dz):
+    return (dx & 255) | ((dy & 255) << 8) | ((dz & 255) << 16)
+
+
+def _tap_product(axes, k, dims):
+    """axes: per spatial axis a list of (kernel index t, offset d). Returns [(torch tap id, packed offset)]."""
+    out = []
+    if dims == 3:
+        for tx, dx in axes[0]:
+            for ty, dy in axes[1]:
+                for tz, dz in axes[2]:
+                    out.append(((tx * k + ty) * k + tz, _pack_off(dx, dy, dz)))
+    else:
+        for tx, dx in axes[0]:
+            for ty, dy in axes[1]:
+                out.append((tx * k + ty, _pack_off(dx, dy, 0)))
+    return out
+
+
+def classes_plain(k, dims, off):
+    """one class; off(t) gives the gather offset of kernel index t"""
+    ax = [[(t, off(t)) for t in range(k)]] * dims
+    return [((0, 0, 0), _tap_product(ax, k, dims))]
+
+
+def classes_up(k, dims):
+    """stride-2 'transposed' pass (ConvTranspose fwd, stride-2 conv dgrad): one class per output parity.
+    written x = 2r + p = 2*xi - 1 + t  =>  p=0: t=1, xi=r ; p=1: t=0, xi=r+1 | t=2, xi=r"""
+    assert k == 3
+    per = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}
+    out = []
+    rz = (0, 1) if dims == 3 else (0,)
+    for px in (0, 1):
+        for py in (0, 1):
+            for pz in rz:
+                ax = [per[px], per[py]] + ([per[pz]] if dims == 3 else [])
+                out.append(((px, py, pz), _tap_product(ax, k, dims)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# parameters: one flat fp32 buffer (+ flat grad) ordered by gradient readiness in backward
+# ------------------------------------------------------------------------------------------------
+class ParamStore:
+    def __init__(self, params, device):
+        self.params = list(params)
+        self.device = device
+        self.offsets, off = {}, 0
+        for p in self.params:
+            self.offsets[id(p)] = off
+            off += p.numel()
+        self.n = off
+        self.n_pad = rup(off, 4)
+        self.zero_index = self.n_pad  # flat_p[n_pad:] stays 0.0 forever (pad source for packing)
+        self.flat_p = torch.zeros(self.n_pad + 4, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros(self.n_pad, dtype=torch.float32, device=device)
+        self.adam_m = self.adam_v = None
+        self.step = 0
+        with torch.no_grad():
+            for p in self.params:
+                o = self.offsets[id(p)]
+                self.flat_p[o:o + p.numel()].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
+        self.attach()
+
+    def attach(self):
+        """make every Parameter a view of the flat buffer"""
+        for p in self.params:
+            o = self.offsets[id(p)]
+            p.data = self.flat_p[o:o + p.numel()].view(p.shape)
+
+    def attached(self):
+        base = self.flat_p.data_ptr()
+        return all(p.data_ptr() == base + 4 * self.offsets[id(p)] and p.device == self.flat_p.device for p in self.params)
+
+    def off(self, p):
+        return self.offsets[id(p)]
+
+    def p_ptr(self, p):
+        return self.flat_p.data_ptr() + 4 * self.offsets[id(p)]
+
+    def g_ptr(self, p):
+        return self.flat_g.data_ptr() + 4 * self.offsets[id(p)]
+
+    def grad_view(self, p):
+        o = self.offsets[id(p)]
+        return self.flat_g[o:o + p.numel()].view(p.shape)
+
+    def version(self):
+        return sum(p._version for p in self.params)
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        """torch.optim.Adam semantics (capstone/volumetric/base_trainer.py:113-114), one launch."""
+        if self.adam_m is None:
+            self.adam_m = torch.zeros_like(self.flat_g)
+            self.adam_v = torch.zeros_like(self.flat_g)
+        self.step += 1
+        nat.call("ctseg_adam_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.adam_m.data_ptr(),
+                 self.adam_v.data_ptr(), self.n, lr, betas[0], betas[1], eps, self.step, grad_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# one implicit-GEMM layer = one conv module, or a fused pair sharing input and geometry
+# ------------------------------------------------------------------------------------------------
+class GemmLayer:
+    def __init__(self, plan, name, transposed, k, stride, cin, parts, cg, need_dgrad=True):
+        """parts: [(weight Parameter, bias Parameter, cout)], cg: gathered channel stride of the input"""
+        self.plan, self.name, self.transposed, self.k, self.s = plan, name, transposed, k, stride
+        self.cin, self.parts, self.cg = cin, parts, cg
+        self.Cn = sum(c for _, _, c in parts)
+        self.dims = plan.dims
+        self.T = k ** self.dims
+        dt = plan.dt
+        e = nat.epc(dt)
+        self.cgd = rup(self.Cn, e)          # gathered stride when dY is the gathered tensor (dgrad / convT wgrad)
+        p = (k - 1) // 2
+        if not transposed:
+            self.fwd_classes = classes_plain(k, self.dims, lambda t: t - p)
+            self.dg_classes = classes_plain(k, self.dims, lambda t: p - t) if stride == 1 else classes_up(k, self.dims)
+        else:
+            assert len(parts) == 1
+            self.fwd_classes = classes_up(k, self.dims) if stride == 2 else classes_plain(k, self.dims, lambda t: p - t)
+            self.dg_classes = classes_plain(k, self.dims, lambda t: t - p)
+        self.wg_taps = classes_plain(k, self.dims, lambda t: t - p)[0][1]
+        assert [t for t, _ in self.wg_taps] == list(range(self.T))
+        self.fwd_pack = plan.packer.add(self, "fwd")
+        self.dg_pack = plan.packer.add(self, "dgrad") if need_dgrad else None  # the stem needs no input gradient
+        self.bias_off = plan.packer.add_bias(self)
+        self.x_dims = None
+
+    # ---- index math for the packer: flat-parameter index of W element for (GEMM row n, gathered channel g, tap id t)
+    def src_index(self, mode, n, g, t):
+        st = self.plan.store
+        cin, T = self.cin, self.T
+        idx = np.full(np.broadcast(n, g, t).shape, st.zero_index, dtype=np.int64)
+        if not self.transposed:
+            r0 = 0
+            for w, _, cout in self.parts:
+                o = st.off(w)
+                if mode == "fwd":    # rows = out channels, gather = in channels
+                    m = (n >= r0) & (n < r0 + cout) & (g < cin)
+                    v = o + ((n - r0) * cin + g) * T + t
+                else:                # dgrad: rows = in channels, gather = dY channels
+                    m = (g >= r0) & (g < r0 + cout) & (n < cin)
+                    v = o + ((g - r0) * cin + n) * T + t
+                idx = np.where(m, v, idx)
+                r0 += cout
+        else:
+            w, _, cout = self.parts[0]
+            o = st.off(w)
+            if mode == "fwd":        # weight [cin][cout][T]: rows = cout, gather = cin
+                m = (n < cout) & (g < cin)
+                v = o + (g * cout + n) * T + t
+            else:
+                m = (n < cin) & (g < cout)
+                v = o + (n * cout + g) * T + t
+            idx = np.where(m, v, idx)
+        return idx
+
+    def rows_gather(self, mode):
+        """(real GEMM rows, gathered channel stride) for a pack mode"""
+        return (self.Cn, self.cg) if mode == "fwd" else (self.cin, self.cgd)
+
+    # ---- geometry ---------------------------------------------------------------------------------
+    def out_dims(self, xd):
+        N, X, Y, Z = xd
+        p = (self.k - 1) // 2
+        if self.transposed:
+            f = (lambda v: v * 2) if self.s == 2 else (lambda v: v)
+        else:
+            f = lambda v: (v + 2 * p - self.k) // self.s + 1
+        return (N, f(X), f(Y), f(Z) if self.dims == 3 else 1)
+
+    def _desc(self, pack, classes, gathered, out, rowgrid, sin, sout, Cn, cg, bias_ptr, add, stats, out_f32):
+        plan = self.plan
+        d = nat.ConvDesc()
+        d.in_, d.w, d.bias, d.out = gathered.ptr(), plan.packer.ptr(pack), bias_ptr, out.ptr()
+        d.add = add.ptr() if add is not None else None
+        d.dtype = plan.dt
+        d.N, d.Xi, d.Yi, d.Zi = gathered.dims
+        d.Xr, d.Yr, d.Zr = rowgrid
+        _, d.Xo, d.Yo, d.Zo = out.dims
+        d.Cg, d.Cn = cg, Cn
+        d.Cn_store = rup(Cn, 4 if out_f32 else nat.epc(plan.dt))
+        assert out.c0 + d.Cn_store <= out.ld, (self.name, out.c0, d.Cn_store, out.ld)
+        d.g_ld, d.o_ld = gathered.ld, out.ld
+        d.add_ld = add.ld if add is not None else 0
+        d.sin, d.sout = sin, sout
+        d.out_f32 = 1 if out_f32 else 0
+        d.add_f32 = 1 if (add is not None and add.t.dtype == torch.float32 and plan.dt != F32) else 0
+        d.nclass = len(classes)
+        bk = 128 // nat.elsize(plan.dt)
+        for i, ((ox, oy, oz), taps) in enumerate(classes):
+            c = d.cls[i]
+            c.ntaps, c.kpad, c.w_off = len(taps), pack["kpads"][i], pack["w_offs"][i]
+            c.ox, c.oy, c.oz = ox, oy, oz
+            for j, (_, off) in enumerate(taps):
+                c.taps[j] = off
+            assert c.kpad % bk == 0
+        if stats is not None:
+            d.stats, d.stats_ld, d.stats_tiles, d.stats_tile0 = stats.partials.data_ptr(), stats.ld, stats.tiles, 0
+        return d
+
+    def emit_fwd(self, x, out=None, want_stats=False, add=None, out_f32=False):
+        plan = self.plan
+        self.x_dims = x.dims
+        od = self.out_dims(x.dims)
+        if out is None:
+            dt = F32 if out_f32 else plan.dt
+            out = new_act(*od, self.Cn, dt, plan.device)
+        assert out.dims == od and out.C == self.Cn, (self.name, out.dims, od)
+        if self.transposed and self.s == 2:
+            rowgrid, sin, sout = x.dims[1:], 1, 2
+        else:
+            rowgrid, sin, sout = od[1:], (1 if self.transposed else self.s), 1
+        stats = None
+        if want_stats:
+            rows = rowgrid[0] * rowgrid[1] * rowgrid[2]
+            tiles = math.ceil(rows / nat.lib().ctseg_conv_tile_rows(self.Cn)) * len(self.fwd_classes)
+            stats = NormStats(plan, od[0], tiles, self.Cn, od[1] * od[2] * od[3])
+        bias_ptr = plan.packer.bias_ptr(self.bias_off)
+        d = self._desc(self.fwd_pack, self.fwd_classes, x, out, rowgrid, sin, sout, self.Cn, self.cg, bias_ptr, add, stats, out_f32)
+        plan.emit("ctseg_conv_igemm", d, keep=(x, out, add, stats))
+        return out, stats
+
+    def emit_dgrad(self, dy, out=None, add=None):
+        """input gradient: gathered = dY (Cn channels), written = dX (cin channels)"""
+        plan = self.plan
+        assert self.dg_pack is not None, f"{self.name}: built without an input-gradient operand"
+        xd = self.x_dims
+        if out is None:
+            out = new_act(*xd, self.cin, plan.dt, plan.device)
+        assert out.dims == xd and out.C == self.cin and dy.C == self.Cn
+        if self.transposed and self.s == 2:       # strided conv over dOut
+            rowgrid, sin, sout = xd[1:], 2, 1
+        elif (not self.transposed) and self.s == 2:  # 8-class pass over dY
+            assert all(a == 2 * b for a, b in zip(xd[1:1 + self.dims], dy.dims[1:1 + self.dims])), \
+                "stride-2 convolutions need even input sizes (as MONAI's UNet does for the skip concat)"
+            rowgrid, sin, sout = dy.dims[1:], 1, 2
+        else:
+            rowgrid, sin, sout = xd[1:], 1, 1
+        d = self._desc(self.dg_pack, self.dg_classes, dy, out, rowgrid, sin, sout, self.cin, self.cgd, None, add, None, False)
+        plan.emit("ctseg_conv_igemm", d, keep=(dy, out, add))
+        return out
+
+    def emit_wgrad(self, x, dy):
+        """weight + bias gradients straight into the flat gradient buffer (deterministic split-K)."""
+        plan, st = self.plan, self.plan.store
+        lib = nat.lib()
+        if not self.transposed:
+            gathered, dyy, cg, A, cn = x, dy, self.cg, self.cin, self.Cn
+            rowgrid, sin = dy.dims[1:], self.s
+        else:
+            assert self.s == 2, "stride-1 transposed conv wgrad not implemented"
+            gathered, dyy, cg, A, cn = dy, x, self.cgd, self.Cn, self.cin
+            rowgrid, sin = x.dims[1:], 2
+        assert dyy.C == cn, (self.name, dyy.C, cn)
+        N = gathered.dims[0]
+        rows = rowgrid[0] * rowgrid[1] * rowgrid[2]
+        bnw = lib.ctseg_wgrad_tile_cols(cn)
+        kpad_w, cn_pad = rup(self.T * cg + 1, 128), rup(cn, bnw)
+        nwg = (kpad_w // 128) * (cn_pad // bnw) * N
+        splits = max(1, min(math.ceil(1024 / nwg), math.ceil(rows / 256), 64))
+        ws = torch.zeros(N * splits * kpad_w * cn_pad, dtype=torch.float32, device=plan.device)
+        d = nat.WgradDesc()
+        d.in_, d.dy, d.ws, d.dtype = gathered.ptr(), dyy.ptr(), ws.data_ptr(), plan.dt
+        d.N, d.Xi, d.Yi, d.Zi = gathered.dims
+        d.Xr, d.Yr, d.Zr = rowgrid
+        d.Cg, d.Cn, d.g_ld, d.d_ld, d.sin = cg, cn, gathered.ld, dyy.ld, sin
+        d.ntaps = self.T
+        for j, (_, off) in enumerate(self.wg_taps):
+            d.taps[j] = off
+        d.splits, d.kpad_w, d.cn_pad = splits, kpad_w, cn_pad
+        plan.emit("ctseg_conv_wgrad", d, keep=(gathered, dyy, ws))
+        if not self.transposed:
+            col0 = 0
+            for w, b, cout in self.parts:
+                plan.emit("ctseg_conv_wgrad_reduce", ws.data_ptr(), N * splits, kpad_w, cn_pad, A, cg, self.T, col0, cout,
+                          st.g_ptr(w), st.g_ptr(b) if b is not None else None)
+                col0 += cout
+        else:
+            w, b, cout = self.parts[0]
+            # R[(t, co)][ci] -> W_T[ci][co][t]; the bias gradient of a transposed conv is sum over dOut: separate pass
+            plan.emit("ctseg_conv_wgrad_reduce", ws.data_ptr(), N * splits, kpad_w, cn_pad, A, cg, self.T, 0, cn,
+                      st.g_ptr(w), None)
+            if b is not None:
+                plan.emit_colsum(dy, st.g_ptr(b))
+
+
+class NormStats:
+    def __init__(self, plan, N, tiles, C, count):
+        self.plan, self.N, self.tiles, self.C, self.count = plan, N, tiles, C, count
+        self.ld = rup(C, nat.lib().ctseg_conv_tile_cols(C))
+        self.partials = torch.zeros((N, tiles, 2, self.ld), dtype=torch.float32, device=plan.device)
+        self.scratch = torch.zeros((N, 64, 2, self.ld), dtype=torch.float64, device=plan.device)
+
+    def emit_finalize(self, col0, C, eps=1e-5):
+        mr = torch.zeros((self.N, C, 2), dtype=torch.float32, device=self.plan.device)
+        self.plan.emit("ctseg_instnorm_finalize", self.partials.data_ptr(), self.N, self.tiles, self.ld, col0, C,
+                       float(self.count), float(eps), self.scratch.data_ptr(), mr.data_ptr(), keep=(self, mr))
+        return mr
+
+
+# ------------------------------------------------------------------------------------------------
+# packed operands: one gather per optimizer step rebuilds every K-contiguous weight block
+# ------------------------------------------------------------------------------------------------
+class Packer:
+    def __init__(self, plan):
+        self.plan = plan
+        self.blocks = []      # (offset, np index array)
+        self.total = 0
+        self.bias_blocks, self.bias_total = [], 0
+        self.buf = self.idx = self.bias_buf = self.bias_idx = None
+        self.dirty = True
+        self.version = None
+
+    def add(self, layer, mode):
+        dt = self.plan.dt
+        bk = 128 // nat.elsize(dt)
+        zero = self.plan.store.zero_index
+        classes = layer.fwd_classes if mode == "fwd" else layer.dg_classes
+        rows, gs = layer.rows_gather(mode)
+        rows_pad = rup(rows, 128)
+        info = {"kpads": [], "w_offs": [], "base": self.total}
+        for _, taps in classes:
+            nt = len(taps)
+            kpad = rup(nt * gs, bk)
+            n_, t_, g_ = np.broadcast_arrays(np.arange(rows_pad)[:, None, None],
+                                             np.array([t for t, _ in taps])[None, :, None],
+                                             np.arange(gs)[None, None, :])
+            src = np.where(n_ < rows, layer.src_index(mode, n_, g_, t_), zero)
+            blk = np.full((rows_pad, kpad), zero, dtype=np.int64)
+            blk[:, :nt * gs] = src.reshape(rows_pad, nt * gs)
+            info["kpads"].append(kpad)
+            info["w_offs"].append(self.total - info["base"])
+            self.blocks.append((self.total, blk.reshape(-1)))
+            self.total += rows_pad * kpad
+        return info
+
+    def add_bias(self, layer):
+        st = self.plan.store
+        off = self.bias_total
+        idx = []
+        for _, b, cout in layer.parts:
+            idx.append(np.arange(cout) + st.off(b) if b is not None else np.full(cout, st.zero_index))
+        idx = np.concatenate(idx)
+        pad = rup(len(idx), 4)
+        full = np.full(pad, st.zero_index, dtype=np.int64)
+        full[:len(idx)] = idx
+        self.bias_blocks.append((off, full))
+        self.bias_total += pad
+        return off
+
+    def ptr(self, info):
+        assert self.buf is not None, "packer.finalize() must run before programs are recorded"
+        return self.buf.data_ptr() + info["base"] * nat.elsize(self.plan.dt)
+
+    def bias_ptr(self, off):
+        assert self.bias_buf is not None
+        return self.bias_buf.data_ptr() + 4 * off
+
+    def finalize(self):
+        dev = self.plan.device
+        self.buf = torch.zeros(max(self.total, 8), dtype=nat.torch_dtype(self.plan.dt), device=dev)
+        self.bias_buf = torch.zeros(max(self.bias_total, 4), dtype=torch.float32, device=dev)
+        idx = np.full(self.total, self.plan.store.zero_index, dtype=np.int32)
+        for off, blk in self.blocks:
+            idx[off:off + len(blk)] = blk
+        self.idx = torch.from_numpy(idx).to(dev)
+        bidx = np.full(max(self.bias_total, 4), self.plan.store.zero_index, dtype=np.int32)
+        for off, blk in self.bias_blocks:
+            bidx[off:off + len(blk)] = blk
+        self.bias_idx = torch.from_numpy(bidx).to(dev)
+        self.n_idx, self.n_bidx = self.total, max(self.bias_total, 4)
+        self.dirty = True
+
+    def refresh(self, force=False):
+        st = self.plan.store
+        ver = st.version()
+        if not (force or self.dirty or ver != self.version):
+            return
+        nat.call("ctseg_gather_cast", st.flat_p.data_ptr(), self.idx.data_ptr(), self.buf.data_ptr(), self.plan.dt, self.n_idx)
+        nat.call("ctseg_gather_cast", st.flat_p.data_ptr(), self.bias_idx.data_ptr(), self.bias_buf.data_ptr(), F32, self.n_bidx)
+        self.dirty, self.version = False, ver

@@ -1,0 +1,435 @@
+"""Plan = the recorded forward/backward programs of one UNet for one (device, dtype, input shape).
+
+Mirrors MONAI 0.3's ``UNet`` execution node by node:
+  _ConvBlock      <- monai Convolution        (conv|convT -> InstanceNorm -> PReLU)
+  _ResUnit        <- monai ResidualUnit       (conv(x) + residual(x))
+  _Level          <- Sequential(down, SkipConnection(sub), up)
+Each node emits C-ABI calls into ``plan.fwd`` / ``plan.bwd`` at build time; nothing here runs per step
+except ``Plan.run``.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _native as nat
+from ._native import BF16, F32
+from .engine import Act, GemmLayer, Packer, ParamStore, new_act, rup
+
+
+def _is_seq(m):
+    """a plain nn.Sequential (a level, or up = Sequential(convT block, ResidualUnit)) — not a Convolution block"""
+    return isinstance(m, nn.Sequential) and not hasattr(m, "conv_only")
+
+
+def _parts(conv):
+    return (conv.weight, conv.bias, conv.out_channels)
+
+
+class _NormAct:
+    """InstanceNorm + PReLU of one conv output: forward apply and the 3-kernel backward."""
+
+    def __init__(self, plan, alpha):
+        self.plan, self.alpha = plan, alpha
+
+    def emit_fwd(self, y, stats, col0, res, out):
+        plan = self.plan
+        self.y = y
+        self.mr = stats.emit_finalize(col0, y.C)
+        if out is None:
+            out = new_act(*y.dims, y.C, plan.dt, plan.device)
+        plan.emit("ctseg_instnorm_prelu_fwd", plan.dt, y.ptr(), y.ld, self.mr.data_ptr(), plan.store.p_ptr(self.alpha),
+                  res.ptr() if res is not None else None, res.ld if res is not None else 0, out.ptr(), out.ld,
+                  y.dims[0], y.S, y.C, keep=(y, res, out))
+        return out
+
+    def emit_bwd(self, g, dy_out=None, g_copy=None):
+        """g = dL/d(activation). Returns dL/dy (raw conv output); alpha's gradient goes to the flat buffer."""
+        plan, y = self.plan, self.y
+        N, S, C = y.dims[0], y.S, y.C
+        P = max(1, min(256, math.ceil(S / 2048)))
+        ld = rup(C, 4)
+        part = torch.zeros((N, P, 3, ld), dtype=torch.float32, device=plan.device)
+        sums = torch.zeros((N, C, 2), dtype=torch.float32, device=plan.device)
+        if dy_out is None:
+            dy_out = new_act(*y.dims, C, plan.dt, plan.device)
+        a_ptr = plan.store.p_ptr(self.alpha)
+        plan.emit("ctseg_instnorm_prelu_bwd_reduce", plan.dt, g.ptr(), g.ld, y.ptr(), y.ld, self.mr.data_ptr(), a_ptr,
+                  part.data_ptr(), P, ld, N, S, C, keep=(g, part))
+        plan.emit("ctseg_instnorm_prelu_bwd_finalize", part.data_ptr(), N, P, ld, C, float(S), sums.data_ptr(),
+                  plan.store.g_ptr(self.alpha), keep=(sums,))
+        plan.emit("ctseg_instnorm_prelu_bwd_apply", plan.dt, g.ptr(), g.ld, y.ptr(), y.ld, self.mr.data_ptr(), a_ptr,
+                  sums.data_ptr(), dy_out.ptr(), dy_out.ld, g_copy.ptr() if g_copy is not None else None,
+                  g_copy.ld if g_copy is not None else 0, N, S, C, keep=(dy_out, g_copy))
+        return dy_out
+
+
+class _ConvBlock:
+    """monai Convolution used as a whole layer (the up path's transposed conv; plain down layers when
+    num_res_units == 0)."""
+
+    def __init__(self, plan, mod, name, cg, need_dgrad=True):
+        self.plan, self.mod = plan, mod
+        self.gemm = GemmLayer(plan, name, mod.is_transposed, mod.kernel_size, mod.strides, mod.cin, [_parts(mod.conv)], cg,
+                              need_dgrad)
+        self.na = None if mod.conv_only else _NormAct(plan, mod.act.weight)
+        self.params = [mod.conv.weight, mod.conv.bias] + ([] if mod.conv_only else [mod.act.weight])
+
+    def emit_fwd(self, x, out=None, out_f32=False):
+        self.x = x
+        if self.na is None:
+            y, _ = self.gemm.emit_fwd(x, out=out, out_f32=out_f32)
+            return y
+        y, stats = self.gemm.emit_fwd(x, want_stats=True)
+        return self.na.emit_fwd(y, stats, 0, None, out)
+
+    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True):
+        dy = g if self.na is None else self.na.emit_bwd(g)
+        self.gemm.emit_wgrad(self.x, dy)
+        self.plan.grads_ready(self.params)
+        if not need_dx:
+            return None
+        return self.gemm.emit_dgrad(dy, out=out, add=out if accumulate else None)
+
+
+class _ResUnit:
+    def __init__(self, plan, mod, name, cg, need_dgrad=True):
+        self.plan, self.mod = plan, mod
+        units = list(mod.conv.children())
+        self.units = units
+        res = mod.residual
+        self.fused = self.res_gemm = None
+        self.identity = isinstance(res, nn.Identity)
+        k, s = mod.kernel_size, mod.strides
+        u0 = units[0]
+        self.params = []
+        if not self.identity and res.kernel_size[0] == k and not u0.conv_only:
+            # residual conv and unit0 conv: same input, same geometry -> one GEMM with 2*C columns
+            self.fused = GemmLayer(plan, name + ".res+unit0", False, k, s, mod.cin, [_parts(res), _parts(u0.conv)], cg, need_dgrad)
+            self.gemms = [self.fused]
+        else:
+            if not self.identity:
+                self.res_gemm = GemmLayer(plan, name + ".residual", False, res.kernel_size[0], s, mod.cin, [_parts(res)], cg,
+                                          need_dgrad)
+            self.gemms = [GemmLayer(plan, name + ".unit0", False, k, s, mod.cin, [_parts(u0.conv)], cg, need_dgrad)]
+        e = nat.epc(plan.dt)
+        for i, u in enumerate(units[1:], 1):
+            self.gemms.append(GemmLayer(plan, f"{name}.unit{i}", False, k, 1, mod.cout, [_parts(u.conv)], rup(mod.cout, e)))
+        self.nas = [None if u.conv_only else _NormAct(plan, u.act.weight) for u in units]
+
+    def emit_fwd(self, x, out=None, out_f32=False):
+        plan, C = self.plan, self.mod.cout
+        self.x = x
+        self.inputs, self.ys = [], []
+        if self.identity:
+            res = x
+        elif self.fused is None:
+            res, _ = self.res_gemm.emit_fwd(x)
+        cur = x
+        n = len(self.units)
+        for i, (g, na) in enumerate(zip(self.gemms, self.nas)):
+            last = i == n - 1
+            self.inputs.append(cur)
+            if na is None:  # last_conv_only: out = conv(cur) + bias + res, fused into the conv epilogue
+                assert last and (self.fused is None or i > 0)
+                y, _ = g.emit_fwd(cur, out=out, add=res, out_f32=out_f32)
+                self.ys.append(y)
+                return y
+            yfull, stats = g.emit_fwd(cur, want_stats=True)
+            if i == 0 and self.fused is not None:
+                res, y, col0 = yfull.slice(0, C), yfull.slice(C, C), C
+            else:
+                y, col0 = yfull, 0
+            self.ys.append(y)
+            cur = na.emit_fwd(y, stats, col0, res if last else None, out if last else None)
+        return cur
+
+    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True):
+        """g = dL/d(out).  out = last_activation + res  =>  both receive g."""
+        plan, C = self.plan, self.mod.cout
+        n = len(self.units)
+        d = g
+        dfused = None
+        if self.fused is not None:
+            dfused = new_act(*self.ys[0].dims, 2 * C, plan.dt, plan.device)   # [ d_res | d_y0 ]
+        for i in range(n - 1, -1, -1):
+            na, gm = self.nas[i], self.gemms[i]
+            last = i == n - 1
+            if na is None:
+                dy = d
+                if i == 0 and self.fused is not None:
+                    raise NotImplementedError("conv_only unit fused with a strided residual")
+            else:
+                tgt = gcopy = None
+                if i == 0 and self.fused is not None:
+                    tgt = dfused.slice(C, C)
+                if last and self.fused is not None:
+                    gcopy = dfused.slice(0, C)      # hand g over to the fused dgrad/wgrad operand for free
+                dy = na.emit_bwd(d, dy_out=tgt, g_copy=gcopy)
+            if i == 0:
+                break
+            gm.emit_wgrad(self.inputs[i], dy)
+            plan.grads_ready([gm.parts[0][0], gm.parts[0][1]] + ([na.alpha] if na is not None else []))
+            d = gm.emit_dgrad(dy)
+        # ---- unit0 (+ residual branch) ----
+        na0 = self.nas[0]
+        alpha0 = [na0.alpha] if na0 is not None else []
+        if self.fused is not None:
+            self.fused.emit_wgrad(self.x, dfused)
+            plan.grads_ready([p for w, b, _ in self.fused.parts for p in (w, b)] + alpha0)
+            if not need_dx:
+                return None
+            return self.fused.emit_dgrad(dfused, out=out, add=out if accumulate else None)
+        g0 = self.gemms[0]
+        g0.emit_wgrad(self.x, dy)
+        ready = [g0.parts[0][0], g0.parts[0][1]] + alpha0
+        if self.res_gemm is not None:
+            self.res_gemm.emit_wgrad(self.x, g)
+            ready += [self.res_gemm.parts[0][0], self.res_gemm.parts[0][1]]
+        plan.grads_ready(ready)
+        if not need_dx:
+            return None
+        if self.identity:
+            assert not accumulate
+            return g0.emit_dgrad(dy, out=out, add=g)            # dx = g + dgrad(dy)
+        dx = g0.emit_dgrad(dy, out=out, add=out if accumulate else None)
+        return self.res_gemm.emit_dgrad(g, out=dx, add=dx)      # += dgrad of the 1x1 residual conv
+
+
+class _Level:
+    """Sequential(down, SkipConnection(sub), up)"""
+
+    def __init__(self, plan, seq, name, cg, is_top):
+        self.plan, self.is_top = plan, is_top
+        down, skip, up = seq[0], seq[1], seq[2]
+        e = nat.epc(plan.dt)
+        mk = lambda m, nm, c, nd=True: (_ResUnit if hasattr(m, "residual") else _ConvBlock)(plan, m, nm, c, nd)
+        # construction order = MONAI's (sub, down, up); gradient-readiness order is up, sub, down
+        sub = skip.submodule
+        self.c1 = down.cout
+        if _is_seq(sub):
+            self.sub = _Level(plan, sub, name + ".1.submodule", rup(self.c1, e), False)
+            self.c2 = sub[2][0].cout if _is_seq(sub[2]) else sub[2].cout
+        else:
+            self.sub = mk(sub, name + ".1.submodule", rup(self.c1, e))
+            self.c2 = sub.cout
+        self.down = mk(down, name + ".0", cg, not is_top or plan.need_input_grad)
+        ccat = self.c1 + self.c2
+        if _is_seq(up):
+            self.up0 = _ConvBlock(plan, up[0], name + ".2.0", rup(ccat, e))
+            self.up1 = _ResUnit(plan, up[1], name + ".2.1", rup(up[0].cout, e))
+        else:
+            self.up0, self.up1 = _ConvBlock(plan, up, name + ".2", rup(ccat, e)), None
+        if plan.dt == BF16 and (self.c1 % e or self.c2 % e):
+            raise nat.NativeError(f"bf16 precision needs channel counts that are multiples of {e} (got {self.c1}, {self.c2})")
+        if plan.dt == F32 and (self.c1 % e or self.c2 % e):
+            raise nat.NativeError(f"channel counts must be multiples of {e} (got {self.c1}, {self.c2})")
+
+    def emit_fwd(self, x, out=None, out_f32=False):
+        plan = self.plan
+        od = self.down.gemms[0].out_dims(x.dims) if hasattr(self.down, "gemms") else self.down.gemm.out_dims(x.dims)
+        self.cat = new_act(*od, self.c1 + self.c2, plan.dt, plan.device)
+        xd = self.down.emit_fwd(x, out=self.cat.slice(0, self.c1))
+        self.sub.emit_fwd(xd, out=self.cat.slice(self.c1, self.c2))
+        if self.up1 is None:
+            return self.up0.emit_fwd(self.cat, out=out, out_f32=out_f32)
+        a = self.up0.emit_fwd(self.cat)
+        return self.up1.emit_fwd(a, out=out, out_f32=out_f32)
+
+    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True):
+        if self.up1 is not None:
+            g = self.up1.emit_bwd(g)
+        gcat = self.up0.emit_bwd(g)
+        self.sub.emit_bwd(gcat.slice(self.c1, self.c2), out=gcat.slice(0, self.c1), accumulate=True)
+        return self.down.emit_bwd(gcat.slice(0, self.c1), out=out, accumulate=accumulate, need_dx=need_dx)
+
+
+class Plan:
+    def __init__(self, engine, N, X, Y, Z):
+        net = engine.net
+        self.engine, self.store, self.dt, self.device = engine, engine.store, engine.dt, engine.device
+        self.dims = net.dimensions
+        self.need_input_grad = False
+        self.packer = Packer(self)
+        self.fwd, self.bwd, self._cur = [], [], None
+        self._keep = []
+        self.ready_marks = []          # (program index in bwd, flat offset end) for gradient all-reduce overlap
+        self.shape = (N, X, Y, Z)
+        cin = net.in_channels
+        self.root = _Level(self, net.model, "model", cin, True)
+        self.packer.finalize()
+        # ---- record programs ----
+        self.x = Act(torch.zeros((N, X, Y, Z, cin), dtype=nat.torch_dtype(self.dt), device=self.device), cin, 0, self.dt)
+        self._cur = self.fwd
+        self.logits = self.root.emit_fwd(self.x, out_f32=True)
+        assert self.logits.t.dtype == torch.float32
+        self.dlogits = new_act(*self.logits.dims, net.out_channels, self.dt, self.device)
+        self._cur = self.bwd
+        self.root.emit_bwd(self.dlogits, need_dx=False)
+        self._cur = None
+
+    # ---- recording ----
+    def emit(self, name, *args, keep=()):
+        fn = getattr(nat.lib(), name)
+        conv = []
+        for a in args:
+            if isinstance(a, (nat.ConvDesc, nat.WgradDesc)):
+                self._keep.append(a)
+                conv.append(a)      # ctypes passes byref through the POINTER argtype
+            else:
+                conv.append(a)
+        self._keep.append(keep)
+        self._cur.append((name, fn, tuple(conv)))
+
+    def emit_colsum(self, x, out_ptr):
+        rows = x.dims[0] * x.S
+        P = max(1, min(256, math.ceil(rows / 4096)))
+        part = torch.zeros((P, rup(x.C, 8)), dtype=torch.float32, device=self.device)
+        self.emit("ctseg_colsum", self.dt, x.ptr(), x.ld, rows, x.C, part.data_ptr(), P, out_ptr, keep=(x, part))
+
+    def grads_ready(self, params):
+        if self._cur is self.bwd:
+            self.ready_marks.append((len(self.bwd), [self.store.off(p) for p in params if p is not None]))
+
+    # ---- running ----
+    @staticmethod
+    def run(prog, stream, lo=0, hi=None):
+        for name, fn, args in prog[lo:hi]:
+            rc = fn(*args, stream)
+            if rc != 0:
+                nat.check(rc, name)
+
+    def load_input(self, x):
+        """(B,Cin,*sp) fp32 NC* tensor -> plan's channels-last storage buffer"""
+        N, X, Y, Z = self.shape
+        cin = self.x.C
+        xs = x.reshape(N, cin, X * Y * Z)
+        if not xs.is_contiguous() or xs.dtype != torch.float32:
+            xs = xs.contiguous().float()
+        nat.call("ctseg_nc_to_cl", xs.data_ptr(), self.x.t.data_ptr(), self.dt, N, cin, X * Y * Z, cin)
+
+    def forward(self, x):
+        self.load_input(x)
+        self.packer.refresh()
+        self.run(self.fwd, nat.stream_ptr())
+        return self.logits
+
+    def backward(self, hooks=None):
+        """runs the recorded backward; ``hooks`` = {program index: callable} fire between ops (DDP overlap)"""
+        st = nat.stream_ptr()
+        if not hooks:
+            self.run(self.bwd, st)
+            return
+        lo = 0
+        for idx in sorted(hooks):
+            self.run(self.bwd, st, lo, idx)
+            hooks[idx]()
+            lo = idx
+        self.run(self.bwd, st, lo)
+
+
+class Engine:
+    """Owns the flat parameter store of one UNet and a cache of plans keyed by input shape."""
+
+    def __init__(self, net):
+        self.net = net
+        self.dt = BF16 if net.precision == "bf16" else F32
+        self.store = None
+        self.device = None
+        self.plans = {}
+        self.last_plan = None
+
+    def _param_order(self):
+        """backward (gradient-readiness) order: up path of the top level first, stem last"""
+        order = []
+
+        def level(seq):
+            down, skip, up = seq[0], seq[1], seq[2]
+            order.extend(reversed(list(up.parameters())))
+            sub = skip.submodule
+            if _is_seq(sub):
+                level(sub)
+            else:
+                order.extend(reversed(list(sub.parameters())))
+            order.extend(reversed(list(down.parameters())))
+
+        level(self.net.model)
+        assert len(order) == len(list(self.net.parameters()))
+        return order
+
+    def ensure(self, device):
+        device = torch.device(device)
+        if self.store is None or self.device != device:
+            self.device = device
+            self.store = ParamStore(self._param_order(), device)
+            self.plans = {}
+        elif not self.store.attached():
+            # someone replaced parameter storage (load_state_dict keeps views; .to()/.float() does not)
+            with torch.no_grad():
+                for p in self.store.params:
+                    o = self.store.off(p)
+                    self.store.flat_p[o:o + p.numel()].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
+            self.store.attach()
+        return self.store
+
+    def plan_for(self, x):
+        self.ensure(x.device)
+        nd = self.net.dimensions
+        if x.ndim != nd + 2 or x.shape[1] != self.net.in_channels:
+            raise ValueError(f"expected input (B,{self.net.in_channels},{'H,W,D' if nd == 3 else 'H,W'}), got {tuple(x.shape)}")
+        N, sp = x.shape[0], tuple(x.shape[2:]) + ((1,) if nd == 2 else ())
+        nlev = len(self.net.channels) - 1
+        for v in sp[:nd]:
+            if v % (2 ** nlev):
+                raise ValueError(f"spatial size {v} is not divisible by 2^{nlev} (the skip concat needs it, as in MONAI)")
+        key = (N,) + sp
+        if key not in self.plans:
+            self.plans[key] = Plan(self, N, *sp)
+        self.last_plan = self.plans[key]
+        return self.last_plan
+
+    # ---- raw (no autograd) API used by the native training step, bench and tests ----
+    def forward(self, x):
+        return self.plan_for(x).forward(x)
+
+    def logits_view(self, plan=None):
+        plan = plan or self.last_plan
+        v = plan.logits.valid()
+        return v[..., 0] if self.net.dimensions == 2 else v
+
+    def backward(self, plan=None, hooks=None):
+        (plan or self.last_plan).backward(hooks)
+
+    # ---- autograd surface (drop-in for loss.backward()) ----
+    def forward_autograd(self, x):
+        plan = self.plan_for(x)
+        params = self.store.params
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            if x.requires_grad:
+                raise NotImplementedError("gradient w.r.t. the input image is not implemented (the reference never needs it)")
+            return _UNetFn.apply(x, self, plan, *params)
+        plan.forward(x)
+        return self.logits_view(plan).clone()
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, engine, plan, *params):
+        plan.forward(x)
+        ctx.engine, ctx.plan = engine, plan
+        out = engine.logits_view(plan)
+        ctx.mark_non_differentiable()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        engine, plan = ctx.engine, ctx.plan
+        fused = getattr(plan, "dlogits_is_current", False)
+        if not fused:
+            C = engine.net.out_channels
+            gv = g if engine.net.dimensions == 3 else g.unsqueeze(-1)
+            plan.dlogits.t[..., :C].copy_(gv.permute(0, 2, 3, 4, 1))
+        plan.dlogits_is_current = False
+        plan.backward()
+        grads = [engine.store.grad_view(p).clone() if p.requires_grad else None for p in engine.store.params]
+        return (None, None, None, *grads)

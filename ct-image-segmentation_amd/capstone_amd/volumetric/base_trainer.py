@@ -1,0 +1,181 @@
+"""Drop-in for reference capstone/volumetric/base_trainer.py: ``BaseUNet3D`` with the same constructor,
+``forward`` / ``training_step`` / ``validation_step`` / ``_shared_step`` / ``configure_optimizers`` /
+``add_model_specific_args`` surface and hyper-parameter names, running on the MI355X engine.
+
+Works as a ``pytorch_lightning.LightningModule`` when Lightning is importable and as a plain
+``nn.Module`` otherwise (Lightning is not in this image); ``fit_step`` is the native step that
+reproduces Lightning 1.0's per-batch order (zero_grad -> training_step -> backward -> [DDP mean of
+gradients] -> Adam.step) without autograd, and is what bench.py times.
+"""
+from argparse import ArgumentParser
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .. import STRUCTURES, segloss
+from .. import _native as nat
+from ..models import UNet
+from ..training.utils import _squash_predictions  # noqa: F401  (same import the reference has)
+from .losses import MultipleLossWrapper3D
+from .metrics import DiceMetricWrapper3D
+from .utils import _squash_masks_3D
+
+try:  # pragma: no cover - Lightning is absent from the build image
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    pl = None
+
+    class _HParams(dict):
+        __getattr__ = dict.__getitem__
+
+    class _Base(nn.Module):
+        """The slice of LightningModule the reference's module uses."""
+
+        def __init__(self):
+            super().__init__()
+            self.hparams = _HParams()
+            self.logged = {}
+
+        def save_hyperparameters(self, *names, frame_locals=None):
+            for n in names:
+                self.hparams[n] = frame_locals.get(n, frame_locals.get("kwargs", {}).get(n))
+
+        def log(self, name, value, **kw):
+            self.logged[name] = value.detach() if torch.is_tensor(value) else value
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+SEED = 12342
+
+
+def _precision(kwargs):
+    p = kwargs.get("precision", "fp32")   # Lightning's Trainer flag arrives through **vars(args) too
+    if p in (16, "16", "bf16", "bf16-mixed", "16-mixed"):
+        return "bf16"
+    if p in (32, "32", "fp32", "32-true", None):
+        return "fp32"
+    raise ValueError(f"unsupported precision {p!r}")
+
+
+class BaseUNet3D(_Base):
+    def __init__(self, filters: List = [16, 32, 64, 128, 256], use_res_units: bool = False, downsample: bool = False,
+                 lr: float = 1e-3, loss_fx: list = ["CrossEntropy"], exclude_missing: bool = False, **kwargs) -> None:
+        super().__init__()
+        assert isinstance(loss_fx, list), "This module expects a list of loss functions"
+        loss_fx.sort()  # consistent order of loss functions (reference :35)
+        names = ("batch_size", "transform_degree", "filters", "use_res_units", "downsample", "lr", "loss_fx", "exclude_missing")
+        if pl is not None:
+            self.save_hyperparameters(*names)
+        else:
+            self.save_hyperparameters(*names, frame_locals=dict(locals()))
+        self._precision = _precision(kwargs)
+        self.unet = self._construct_model()
+        self.loss_func = MultipleLossWrapper3D(losses=loss_fx, exclude_missing=exclude_missing)
+        self.dice_score = DiceMetricWrapper3D()
+        self.reducer = None      # capstone_amd.distributed.GradAllReducer when data-parallel
+
+    @property
+    def _n_classes(self):
+        return len(STRUCTURES) + 1
+
+    def _construct_model(self):
+        # reference :58-72 — in_channels=1, strides for a 5-entry filter list, num_res_units hard-wired to 2
+        return UNet(dimensions=3, in_channels=1, out_channels=self._n_classes, channels=self.hparams.filters,
+                    strides=[2, 2, 2, 2], num_res_units=2, precision=self._precision)
+
+    def forward(self, x):
+        return self.unet(x)
+
+    def training_step(self, batch, batch_idx=0):
+        _, _, _, _, loss = self._shared_step(batch, is_training=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx=0):
+        self._shared_step(batch, is_training=False)
+
+    def _shared_step(self, batch, is_training: bool):
+        (images, masks, mask_indicator) = batch
+        masks = _squash_masks_3D(masks, self._n_classes, self.device)
+        mask_indicator = mask_indicator.type_as(images)
+        prefix = "train" if is_training else "val"
+        prediction = self.forward(images)
+        prediction._ctseg_plan = self.unet.engine().last_plan
+        loss_dict = self.loss_func(input=prediction, target=masks, mask_indicator=mask_indicator)
+        total_loss = torch.stack(list(loss_dict.values())).sum()
+        for name, loss_value in loss_dict.items():
+            self.log(f"{name} Loss ({prefix})", loss_value, on_step=False, on_epoch=True)
+        self._log_dice_scores(prediction, masks, mask_indicator, prefix)
+        return images, masks, mask_indicator, prediction, total_loss
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=self.hparams.lr)
+
+    def _log_dice_scores(self, prediction, masks, mask_indicator, prefix):
+        # reference :116-132 clones 1 GB of logits, softmaxes, argmaxes and one-hots twice; the fused loss pass
+        # already counted |pred==c & true==c|, |pred==c|, |true==c| with the same softmax->argmax tie rule.
+        with torch.no_grad():
+            eng = getattr(prediction._ctseg_plan, "_ctseg_loss", None)
+            dice_mean, dice_per_class = eng.dice_metric()
+            for structure, score in zip(STRUCTURES, dice_per_class):
+                self.log(f"{structure} Dice ({prefix})", score, on_step=False, on_epoch=True)
+            self.log(f"Mean Dice Score ({prefix})", dice_mean, on_step=False, on_epoch=True)
+
+    # ---- native step: what Lightning's loop does per batch, without autograd -------------------------
+    def fit_step(self, batch, betas=(0.9, 0.999), eps=1e-8):
+        images, masks, mask_indicator = batch
+        nat.require_gpu(images, "fit_step")
+        eng = self.unet.engine()
+        plan = eng.plan_for(images)
+        lab_u8, _, hist = segloss.squash_masks(masks, self._n_classes, want_i64=False)
+        logits = plan.forward(images)
+        le = getattr(plan, "_ctseg_loss", None)
+        if le is None:
+            le = plan._ctseg_loss = segloss.SegLossEngine(images.device, images.shape[0], logits.S, self._n_classes)
+        le.set_labels(lab_u8, hist)
+        names = list(self.loss_func.names)
+        dl = plan.dlogits
+        if len(names) == 1 and names[0] in ("CrossEntropy", "WeightedCrossEntropy"):
+            le.fused_ce(logits.ptr(), logits.ld, dl.ptr(), dl.ld, plan.dt, weighted=names[0] != "CrossEntropy")
+            vals = le.loss_values(names)
+        else:
+            le.stats(logits.ptr(), logits.ld, weighted_too="WeightedCrossEntropy" in names)
+            vals = le.loss_values(names, self.loss_func.exclude_missing, mask_indicator.float())
+            le.build_coef({n: 1.0 for n in names})
+            le.grad(logits.ptr(), logits.ld, dl.ptr(), dl.ld, plan.dt)
+        if self.reducer is not None:
+            plan.backward(self.reducer.hooks(plan))
+            scale = self.reducer.finish()
+        else:
+            plan.backward()
+            scale = 1.0
+        eng.store.adam_step(self.hparams.lr, betas, eps, grad_scale=scale)
+        plan.packer.dirty = True
+        total = torch.stack([vals[n] for n in names]).sum()
+        dice_mean, dice_per_class = le.dice_metric()
+        for n in names:
+            self.log(f"{n} Loss (train)", vals[n])
+        self.log("Mean Dice Score (train)", dice_mean)
+        self.log("Dice per class (train)", dice_per_class)
+        return total
+
+    @staticmethod
+    def add_model_specific_args(parent_parser):
+        """Same flags and defaults as reference :134-182."""
+        parser = ArgumentParser(parents=[parent_parser], add_help=False)
+        parser.add_argument("--batch_size", type=int, default=1, help="Batch size")
+        parser.add_argument("--transform_degree", type=int, default=0,
+                            help="The degree of transforms/data augmentation to be applied")
+        parser.add_argument("--filters", nargs=5, type=int, default=[64, 128, 256, 512, 1024],
+                            help="A sqeuence of number of filters for the downsampling path in UNet")
+        parser.add_argument("--use_res_units", action="store_true", default=False, help="For using residual units in UNet")
+        parser.add_argument("--downsample", action="store_true", default=False,
+                            help="For using a 1x1 convolution to downsample the input before UNet")
+        parser.add_argument("--lr", type=float, default=1e-3, help="Learning rate")
+        parser.add_argument("--loss_fx", nargs="+", type=str, default="CrossEntropy", help="Loss function")
+        parser.add_argument("--exclude_missing", action="store_true", default=False,
+                            help="Exclude missing annotations from loss computation as described in AnatomyNet")
+        return parser

@@ -1,0 +1,383 @@
+// Implicit-GEMM convolution pass for gfx950 (MI355X): Conv3d / ConvTranspose3d forward and
+// input-gradient of the MONAI UNet the reference trains (capstone/volumetric/base_trainer.py:65-72).
+//
+//   out[voxel(row)][n] = bias[n] + add[voxel(row)][n] + sum_{slot,c} in[row*sin + d(slot)][c] * W[n][slot*Cg + c]
+//
+// One workgroup (4 waves) owns BM consecutive rows of one sample's row grid x BN output channels.
+// Per 128-byte K stage: the im2col rows (bounds-checked 16-byte gathers of channels-last voxels)
+// and the K-contiguous weight rows are staged global -> registers -> LDS (double buffered, one
+// barrier per stage), XOR-swizzled so that every ds_read_b128 of an MFMA fragment is bank-conflict
+// free, and consumed by v_mfma_f32_16x16x32_bf16 (bf16 storage) or v_mfma_f32_16x16x4_f32 (fp32
+// storage: bit-for-bit an fmaf chain, the parity mode).  The weight tile is the FIRST MFMA operand,
+// so each lane ends up with 4 consecutive output channels of one voxel -> channels-last epilogue.
+// Epilogue: + bias, per-(tile, channel) sum / sum-of-squares partials for InstanceNorm, transpose
+// through LDS, optional addend (residual / gradient accumulation), 16-byte coalesced stores.
+#include "ctseg_dev.h"
+
+namespace ctseg {
+
+struct ConvKArgs {
+  const char* in;
+  const char* w;
+  const float* bias;
+  char* out;
+  const char* add;
+  float* stats;
+  int N, Xi, Yi, Zi, Xr, Yr, Zr, Xo, Yo, Zo;
+  int Cg, Cn, Cn_store, g_ld, o_ld, add_ld;
+  int sin, sout;
+  int rows, tiles;
+  int out_f32, add_f32;
+  int stats_ld, stats_tiles, stats_tile0;
+  ctseg_conv_class cls[CTSEG_MAX_CLASSES];
+};
+
+template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag);
+template <> __device__ __forceinline__ void mma16<BF16>(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, xfrag), acc,
+                                                0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wfrag[s]), __uint_as_float(xfrag[s]), acc, 0, 0, 0);
+}
+
+template <int BM, int BN> struct ConvSmem {
+  static constexpr int BKB = 128;
+  static constexpr int STAGE = (BM + BN) * BKB;
+  static constexpr int CROW = BN * 4 + 16;  // epilogue row pitch (sized for fp32 output)
+  static constexpr int MAIN = (2 * STAGE > BM * CROW) ? 2 * STAGE : BM * CROW;
+  static constexpr int STATS = 4 * 2 * BN * 4;
+  static constexpr int ROWTAB = BM * 8;
+  static constexpr int TOTAL = MAIN + STATS + ROWTAB + 32 * 4;
+};
+
+template <typename T, int BM, int BN, int WGM, int WGN, bool SMALLC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs P) {
+  constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
+  constexpr int BKB = 128, BK = BKB / SZ, CH = BKB / 16, RPR = 256 / CH;
+  constexpr int AR = BM / RPR;
+  constexpr int BR = (BN + RPR - 1) / RPR;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN, MT = WTM / 16, NT = WTN / 16;
+  using SM = ConvSmem<BM, BN>;
+  static_assert(WGM * WGN == 4 && MT >= 1 && NT >= 1, "4 waves per workgroup");
+
+  __shared__ __attribute__((aligned(16))) char smem[SM::TOTAL];
+  char* const sA0 = smem;                    // [2][BM][128] then [2][BN][128]
+  char* const sB0 = smem + 2 * BM * BKB;
+  float* const sStats = reinterpret_cast<float*>(smem + SM::MAIN);
+  int* const sRow = reinterpret_cast<int*>(smem + SM::MAIN + SM::STATS);  // [BM][2]
+  int* const sTap = sRow + BM * 2;                                        // [32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int tile = blockIdx.x % P.tiles, n = blockIdx.x / P.tiles;
+  const int col0 = blockIdx.y * BN;
+  const ctseg_conv_class& K = P.cls[blockIdx.z];
+  const int ntaps = K.ntaps, kpad = K.kpad;
+
+  // ---- per-tile row table: gathered base coordinates of each GEMM row -------------------------
+  for (int r = tid; r < BM; r += 256) {
+    int ri = tile * BM + r;
+    int xy = 0, z = -(1 << 24);
+    if (ri < P.rows) {
+      int zr = ri % P.Zr, t = ri / P.Zr;
+      int yr = t % P.Yr, xr = t / P.Yr;
+      xy = xr | (yr << 16);
+      z = zr;
+    }
+    sRow[2 * r] = xy;
+    sRow[2 * r + 1] = z;
+  }
+  if (tid < 32) sTap[tid] = (tid < ntaps) ? K.taps[tid] : 0;
+  __syncthreads();
+
+  const int q8 = tid % CH, r0 = tid / CH;
+  int rxy[AR], rz[AR];
+#pragma unroll
+  for (int j = 0; j < AR; ++j) {
+    int xy = sRow[2 * (r0 + j * RPR)], z = sRow[2 * (r0 + j * RPR) + 1];
+    rxy[j] = ((xy & 0xffff) * P.sin) | (((xy >> 16) * P.sin) << 16);
+    rz[j] = (z < 0) ? z : z * P.sin;
+  }
+  // K position of this thread's 16-byte chunk: slot (tap) and channel, advanced stage by stage
+  int slot = (q8 * EPC) / P.Cg, ci = (q8 * EPC) % P.Cg;
+  const int64_t nbase = (int64_t)n * P.Xi;
+  const char* wrow = P.w + (K.w_off + (int64_t)(col0 + r0) * kpad + q8 * EPC) * SZ;
+
+  u32x4 ra[AR], rb[BR];
+  auto gload = [&](int s) {
+    if constexpr (!SMALLC) {
+      int tp = (slot < ntaps) ? sTap[slot & 31] : 0;
+      const bool sv = slot < ntaps;
+      const int dx = (int)(int8_t)(tp & 0xff), dy = (int)(int8_t)((tp >> 8) & 0xff), dz = (int)(int8_t)((tp >> 16) & 0xff);
+#pragma unroll
+      for (int j = 0; j < AR; ++j) {
+        int xi = (rxy[j] & 0xffff) + dx, yi = (rxy[j] >> 16) + dy, zi = rz[j] + dz;
+        bool ok = sv && (unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) {
+          int64_t vox = ((nbase + xi) * P.Yi + yi) * P.Zi + zi;
+          v = *reinterpret_cast<const u32x4*>(P.in + (vox * P.g_ld + ci) * SZ);
+        }
+        ra[j] = v;
+      }
+      ci += BK;
+      while (ci >= P.Cg) { ci -= P.Cg; ++slot; }
+    } else {
+      // channel count not a multiple of the 16-byte chunk (Cin = 1 stem): element-wise gather
+      const int kp0 = s * BK + q8 * EPC;
+#pragma unroll
+      for (int j = 0; j < AR; ++j) {
+        uint32_t e[EPC];
+#pragma unroll
+        for (int t = 0; t < EPC; ++t) {
+          int kp = kp0 + t, sl = kp / P.Cg, c = kp - sl * P.Cg;
+          uint32_t val = 0u;
+          if (sl < ntaps) {
+            int tp = sTap[sl & 31];
+            int xi = (rxy[j] & 0xffff) + (int)(int8_t)(tp & 0xff), yi = (rxy[j] >> 16) + (int)(int8_t)((tp >> 8) & 0xff),
+                zi = rz[j] + (int)(int8_t)((tp >> 16) & 0xff);
+            if ((unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi) {
+              int64_t vox = ((nbase + xi) * P.Yi + yi) * P.Zi + zi;
+              const char* p = P.in + (vox * P.g_ld + c) * SZ;
+              if constexpr (SZ == 4) val = *reinterpret_cast<const uint32_t*>(p);
+              else val = *reinterpret_cast<const unsigned short*>(p);
+            }
+          }
+          e[t] = val;
+        }
+        u32x4 v;
+        if constexpr (SZ == 4) { v[0] = e[0]; v[1] = e[1]; v[2] = e[2]; v[3] = e[3]; }
+        else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = e[2 * t] | (e[2 * t + 1] << 16);
+        }
+        ra[j] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (BN >= RPR || r0 + j * RPR < BN)
+        v = *reinterpret_cast<const u32x4*>(wrow + ((int64_t)j * RPR * kpad + (int64_t)s * BK) * SZ);
+      rb[j] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+    char* a = sA0 + buf * BM * BKB;
+    char* b = sB0 + buf * BN * BKB;
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+      int r = r0 + j * RPR;
+      *reinterpret_cast<u32x4*>(a + r * BKB + ((q8 ^ ((r >> 1) & 7)) << 4)) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      int r = r0 + j * RPR;
+      if (BN >= RPR || r < BN) *reinterpret_cast<u32x4*>(b + r * BKB + ((q8 ^ ((r >> 1) & 7)) << 4)) = rb[j];
+    }
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nst = kpad / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const int swz = (r16 >> 1) & 7;
+  for (int s = 0; s < nst; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nst) gload(s + 1);
+    const char* a = sA0 + buf * BM * BKB + (wm * WTM + r16) * BKB;
+    const char* b = sB0 + buf * BN * BKB + (wn * WTN + r16) * BKB;
+#pragma unroll
+    for (int c = 0; c < BKB / 64; ++c) {
+      const int off = ((4 * c + q4) ^ swz) << 4;
+      u32x4 xf[MT], wf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const u32x4*>(a + i * 16 * BKB + off);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4*>(b + j * 16 * BKB + off);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) mma16<T>(acc[j][i], wf[j], xf[i]);
+    }
+    if (s + 1 < nst) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  // lane holds, for MFMA tile (j,i): voxel row = wm*WTM + i*16 + r16, channels wn*WTN + j*16 + 4*q4 + {0..3}
+  const bool of32 = P.out_f32 != 0;
+  const int OSZ = of32 ? 4 : SZ;
+  const int crow = BN * OSZ + 16;
+  float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ch = col0 + wn * WTN + j * 16 + 4 * q4;
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bv[e] = (P.bias != nullptr && ch + e < P.Cn) ? P.bias[ch + e] : 0.f;
+      ssum[j][e] = 0.f;
+      ssq[j][e] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int r = wm * WTM + i * 16 + r16;
+      const bool rv = sRow[2 * r + 1] >= 0;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = acc[j][i][e] + bv[e];
+        if (rv) { ssum[j][e] += v[e]; ssq[j][e] += v[e] * v[e]; }
+      }
+      char* cp = smem + r * crow + (wn * WTN + j * 16 + 4 * q4) * OSZ;
+      if (of32 || SZ == 4) {
+        *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+        *reinterpret_cast<u32x2*>(cp) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      }
+    }
+  }
+  if (P.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = ssum[j][e], b = ssq[j][e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (r16 == 0) {
+          const int c = wn * WTN + j * 16 + 4 * q4 + e;
+          sStats[(wm * 2 + 0) * BN + c] = a;
+          sStats[(wm * 2 + 1) * BN + c] = b;
+        }
+      }
+  }
+  __syncthreads();
+  if (P.stats != nullptr && tid < 2 * BN) {
+    const int which = tid / BN, c = tid % BN;
+    float a = 0.f;
+#pragma unroll
+    for (int m = 0; m < WGM; ++m) a += sStats[(m * 2 + which) * BN + c];
+    const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + (int64_t)blockIdx.z * P.tiles + tile;
+    P.stats[(slot_t * 2 + which) * P.stats_ld + col0 + c] = a;
+  }
+  {
+    const int EPO = 16 / OSZ;               // output elements per 16-byte chunk
+    const int cpr = BN / EPO;                // chunks per tile row
+    const bool af32 = P.add_f32 != 0;
+    const int ASZ = af32 ? 4 : SZ;
+    for (int idx = tid; idx < BM * cpr; idx += 256) {
+      const int r = idx / cpr, cc = idx - r * cpr;
+      const int ch = col0 + cc * EPO;
+      const int z = sRow[2 * r + 1];
+      if (z < 0 || ch >= P.Cn_store) continue;
+      const int xy = sRow[2 * r];
+      const int64_t vox = (((int64_t)n * P.Xo + (xy & 0xffff) * P.sout + K.ox) * P.Yo + (xy >> 16) * P.sout + K.oy) * P.Zo +
+                          z * P.sout + K.oz;
+      const char* cp = smem + r * crow + cc * 16;
+      char* op = P.out + (vox * P.o_ld + ch) * OSZ;
+      if (P.add == nullptr) {
+        *reinterpret_cast<u32x4*>(op) = *reinterpret_cast<const u32x4*>(cp);
+      } else {
+        float v[8], a[8];
+        load_n_as_float(cp, of32 || SZ == 4, EPO, v);
+        load_n_as_float(P.add + (vox * P.add_ld + ch) * ASZ, af32 || SZ == 4, EPO, a);
+        for (int e = 0; e < EPO; ++e) v[e] += a[e];
+        if (of32 || SZ == 4) store_chunk<float>(op, v);
+        else store_chunk<BF16>(op, v);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+static int launch_cfg(const ConvKArgs& a, bool smallc, int nclass, hipStream_t st) {
+  dim3 grid((unsigned)(a.tiles * a.N), (unsigned)((a.Cn + BN - 1) / BN), (unsigned)nclass);
+  if (smallc) hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, false>), grid, dim3(256), 0, st, a);
+  return 0;
+}
+
+template <typename T> static int launch_dtype(ConvKArgs& a, bool smallc, int nclass, hipStream_t st) {
+  const int bm = ctseg_conv_tile_rows(a.Cn);
+  a.tiles = (a.rows + bm - 1) / bm;
+  if (a.Cn <= 16) return launch_cfg<T, 256, 16, 4, 1>(a, smallc, nclass, st);
+  if (a.Cn <= 32) return launch_cfg<T, 256, 32, 4, 1>(a, smallc, nclass, st);
+  if (a.Cn <= 64) return launch_cfg<T, 128, 64, 2, 2>(a, smallc, nclass, st);
+  return launch_cfg<T, 128, 128, 2, 2>(a, smallc, nclass, st);
+}
+
+}  // namespace ctseg
+
+using namespace ctseg;
+
+extern "C" int ctseg_conv_tile_rows(int32_t Cn) { return Cn <= 32 ? 256 : 128; }
+extern "C" int ctseg_conv_tile_cols(int32_t Cn) { return Cn <= 16 ? 16 : Cn <= 32 ? 32 : Cn <= 64 ? 64 : 128; }
+
+extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
+  CTSEG_REQUIRE(d != nullptr && d->in && d->w && d->out, "conv_igemm: null pointer");
+  CTSEG_REQUIRE(d->dtype == CTSEG_F32 || d->dtype == CTSEG_BF16, "conv_igemm: bad dtype %d", d->dtype);
+  const int SZ = d->dtype == CTSEG_F32 ? 4 : 2, EPC = 16 / SZ, BK = 128 / SZ;
+  const int OSZ = d->out_f32 ? 4 : SZ, EPO = 16 / OSZ;
+  CTSEG_REQUIRE(d->nclass >= 1 && d->nclass <= CTSEG_MAX_CLASSES, "conv_igemm: nclass %d", d->nclass);
+  CTSEG_REQUIRE(d->N > 0 && d->Cg > 0 && d->Cn > 0 && d->Xr > 0 && d->Yr > 0 && d->Zr > 0, "conv_igemm: empty dims");
+  CTSEG_REQUIRE(d->Xr < 65536 && d->Yr < 32768 && d->sin >= 1 && d->sin <= 2 && d->sout >= 1 && d->sout <= 2,
+                "conv_igemm: grid/stride out of range");
+  CTSEG_REQUIRE((int64_t)d->Xr * d->sin < 65536 && (int64_t)d->Yr * d->sin < 32768, "conv_igemm: coordinates overflow 16 bits");
+  CTSEG_REQUIRE(d->Cn_store >= d->Cn && d->Cn_store % EPO == 0 && d->Cn_store <= d->o_ld, "conv_igemm: Cn_store %d", d->Cn_store);
+  CTSEG_REQUIRE(d->o_ld % EPO == 0 && ((uintptr_t)d->out % 16) == 0, "conv_igemm: out not 16-byte chunked");
+  const bool smallc = (d->Cg % EPC) != 0 || (d->g_ld % EPC) != 0 || ((uintptr_t)d->in % 16) != 0;
+  CTSEG_REQUIRE(d->g_ld >= d->Cg, "conv_igemm: g_ld < Cg");
+  if (d->add) {
+    const int ASZ = d->add_f32 ? 4 : SZ;
+    CTSEG_REQUIRE((d->add_ld * ASZ) % (EPO * ASZ) == 0 && ((uintptr_t)d->add % (EPO * ASZ)) == 0 && d->add_ld >= d->Cn_store,
+                  "conv_igemm: addend layout");
+  }
+  CTSEG_REQUIRE((int64_t)d->Xr * d->Yr * d->Zr < (1ll << 31), "conv_igemm: row grid too large");
+  int mox = 0, moy = 0, moz = 0;
+  for (int c = 0; c < d->nclass; ++c) {
+    const ctseg_conv_class& k = d->cls[c];
+    mox = k.ox > mox ? k.ox : mox; moy = k.oy > moy ? k.oy : moy; moz = k.oz > moz ? k.oz : moz;
+    CTSEG_REQUIRE(k.ntaps >= 1 && k.ntaps <= CTSEG_MAX_TAPS, "conv_igemm: class %d ntaps %d", c, k.ntaps);
+    CTSEG_REQUIRE(k.kpad % BK == 0 && k.kpad >= k.ntaps * d->Cg, "conv_igemm: class %d kpad %d", c, k.kpad);
+    CTSEG_REQUIRE(((k.w_off * SZ) % 16) == 0, "conv_igemm: class %d weight offset unaligned", c);
+    CTSEG_REQUIRE(k.ox >= 0 && k.oy >= 0 && k.oz >= 0 && k.ox < d->sout && k.oy < d->sout && k.oz < d->sout,
+                  "conv_igemm: class %d output parity", c);
+  }
+  CTSEG_REQUIRE((int64_t)(d->Xr - 1) * d->sout + mox < d->Xo && (int64_t)(d->Yr - 1) * d->sout + moy < d->Yo &&
+                    (int64_t)(d->Zr - 1) * d->sout + moz < d->Zo,
+                "conv_igemm: row grid * sout exceeds written dims");
+  ConvKArgs a;
+  a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out;
+  a.add = (const char*)d->add; a.stats = d->stats;
+  a.N = d->N; a.Xi = d->Xi; a.Yi = d->Yi; a.Zi = d->Zi; a.Xr = d->Xr; a.Yr = d->Yr; a.Zr = d->Zr;
+  a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo;
+  a.Cg = d->Cg; a.Cn = d->Cn; a.Cn_store = d->Cn_store; a.g_ld = d->g_ld; a.o_ld = d->o_ld; a.add_ld = d->add_ld;
+  a.sin = d->sin; a.sout = d->sout; a.rows = d->Xr * d->Yr * d->Zr; a.tiles = 0;
+  a.out_f32 = d->out_f32; a.add_f32 = d->add_f32;
+  a.stats_ld = d->stats_ld; a.stats_tiles = d->stats_tiles; a.stats_tile0 = d->stats_tile0;
+  for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
+  if (d->stats) {
+    const int bm = ctseg_conv_tile_rows(d->Cn);
+    const int tiles = (a.rows + bm - 1) / bm;
+    const int bn = ctseg_conv_tile_cols(d->Cn);
+    CTSEG_REQUIRE(d->stats_tile0 + tiles * d->nclass <= d->stats_tiles && d->stats_ld >= ((d->Cn + bn - 1) / bn) * bn,
+                  "conv_igemm: stats partial layout (need stats_ld >= roundup(Cn, tile cols))");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == CTSEG_F32) launch_dtype<float>(a, smallc, d->nclass, st);
+  else launch_dtype<BF16>(a, smallc, d->nclass, st);
+  CTSEG_LAUNCH_CHECK("conv_igemm");
+  return 0;
+}

@@ -1,0 +1,286 @@
+// Weight-gradient pass for gfx950: R[slot*Cg + a][b] = sum_rows in[row*sin + d(slot)][a] * dy[row][b]
+// (autograd's Conv3d / ConvTranspose3d weight + bias backward in the reference's training step,
+// capstone/volumetric/base_trainer.py:80-82 -> loss.backward()).
+//
+// The contraction runs over voxels (rows), which is the SLOW axis of both channels-last operands, so
+// the MFMA fragments need a transpose: bf16 uses ds_read_b64_tr_b16 (hardware transposed LDS read,
+// 4 voxels x 16 channels per 16-lane group); fp32 feeds v_mfma_f32_16x16x4_f32 one element per lane,
+// which needs none.  A workgroup owns 128 K-rows x BNW columns and a contiguous row range of one
+// sample (split-K); partial tiles go to fp32 slabs that ctseg_conv_wgrad_reduce sums in fixed order
+// (deterministic) straight into the torch weight layout.  K index ntaps*Cg is a virtual all-ones
+// gathered channel, so its row of R is the bias gradient.
+#include "ctseg_dev.h"
+
+namespace ctseg {
+
+struct WgradKArgs {
+  const char* in;
+  const char* dy;
+  float* ws;
+  int N, Xi, Yi, Zi, Xr, Yr, Zr;
+  int Cg, Cn, g_ld, d_ld, sin, ntaps;
+  int rows, splits, rows_per_split;
+  int kpad_w, cn_pad, d_valid;
+  int sx, sy, sz;  // mixed-radix decomposition of a 32-row step
+  int taps[CTSEG_MAX_TAPS];
+};
+
+template <typename T, int BNW> struct WgradCfg {
+  static constexpr int SZ = TT<T>::SZ;
+  static constexpr int PA = 128 * SZ + (SZ == 2 ? 32 : 64);
+  static constexpr int PD = BNW * SZ + ((SZ == 2) ? (BNW == 16 ? 64 : 32) : 64);
+  static constexpr int STAGE = 32 * (PA + PD);
+};
+
+template <typename T, int BNW, int WK, int WC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
+  constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
+  using CF = WgradCfg<T, BNW>;
+  constexpr int PA = CF::PA, PD = CF::PD;
+  constexpr int KT = 128 / WK / 16, CT = BNW / WC / 16;
+  constexpr int ACPR = 128 / EPC;            // 16-byte chunks per gathered row (16 bf16 / 32 fp32)
+  constexpr int AJ = 32 * ACPR / 256;        // gathered chunks per thread per stage (2 / 4)
+  constexpr int ARS = 256 / ACPR;            // row stride between a thread's chunks (16 / 8)
+  constexpr int DCPR = BNW / EPC;            // chunks per dy row
+  constexpr int DJ = (32 * DCPR + 255) / 256;
+  static_assert(WK * WC == 4 && KT >= 1 && CT >= 1, "4 waves");
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * CF::STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / WC, wc = wave % WC;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int kblock = blockIdx.x, col0 = blockIdx.y * BNW;
+  const int n = blockIdx.z / P.splits, sp = blockIdx.z % P.splits;
+  const int mstart = sp * P.rows_per_split;
+  int mend = mstart + P.rows_per_split;
+  if (mend > P.rows) mend = P.rows;
+  const int nst = (mend > mstart) ? (mend - mstart + 31) / 32 : 0;
+
+  // ---- fixed K position of this thread's gathered chunks -----------------------------------------
+  const int acc_c = tid % ACPR, arow0 = tid / ACPR;
+  const int kpos = kblock * 128 + acc_c * EPC;
+  const int ktot = P.ntaps * P.Cg;
+  const int slot = kpos / P.Cg, ci = kpos - slot * P.Cg;
+  const bool kvalid = kpos < ktot, kones = kpos == ktot;
+  int dx = 0, dy_ = 0, dz = 0;
+  if (kvalid) {
+    const int tp = P.taps[slot];
+    dx = (int)(int8_t)(tp & 0xff); dy_ = (int)(int8_t)((tp >> 8) & 0xff); dz = (int)(int8_t)((tp >> 16) & 0xff);
+  }
+  int cx[AJ], cy[AJ], cz[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    int m = mstart + arow0 + j * ARS;
+    cz[j] = m % P.Zr; int t = m / P.Zr;
+    cy[j] = t % P.Yr; cx[j] = t / P.Yr;
+  }
+  const int64_t nbase = (int64_t)n * P.Xi;
+  const char* dbase = P.dy + ((int64_t)n * P.rows * P.d_ld + col0) * SZ;
+
+  u32x4 ra[AJ], rd[DJ];
+  u32x4 ones = {0u, 0u, 0u, 0u};
+  ones[0] = (SZ == 4) ? 0x3f800000u : 0x3f80u;
+  auto gload = [&](int s) {
+    const int mb = mstart + s * 32;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int m = mb + arow0 + j * ARS;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (m < mend) {
+        if (kvalid) {
+          const int xi = cx[j] * P.sin + dx, yi = cy[j] * P.sin + dy_, zi = cz[j] * P.sin + dz;
+          if ((unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi) {
+            const int64_t vox = ((nbase + xi) * P.Yi + yi) * P.Zi + zi;
+            v = *reinterpret_cast<const u32x4*>(P.in + (vox * P.g_ld + ci) * SZ);
+          }
+        } else if (kones) {
+          v = ones;
+        }
+      }
+      ra[j] = v;
+      // advance this chunk's row by 32 (mixed radix z,y,x)
+      cz[j] += P.sz; if (cz[j] >= P.Zr) { cz[j] -= P.Zr; ++cy[j]; }
+      cy[j] += P.sy; if (cy[j] >= P.Yr) { cy[j] -= P.Yr; ++cx[j]; }
+      cx[j] += P.sx;
+    }
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+      const int idx = tid + j * 256;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx < 32 * DCPR) {
+        const int r = idx / DCPR, dc = idx - r * DCPR;
+        const int m = mb + r;
+        if (m < mend && col0 + dc * EPC < P.d_valid)
+          v = *reinterpret_cast<const u32x4*>(dbase + ((int64_t)m * P.d_ld + dc * EPC) * SZ);
+      }
+      rd[j] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+    char* a = smem + buf * CF::STAGE;
+    char* d = a + 32 * PA;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) *reinterpret_cast<u32x4*>(a + (arow0 + j * ARS) * PA + acc_c * 16) = ra[j];
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+      const int idx = tid + j * 256;
+      if (idx < 32 * DCPR) {
+        const int r = idx / DCPR, dc = idx - r * DCPR;
+        *reinterpret_cast<u32x4*>(d + r * PD + dc * 16) = rd[j];
+      }
+    }
+  };
+
+  f32x4 acc[KT][CT];
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nst > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nst) gload(s + 1);
+    const char* a = smem + buf * CF::STAGE;
+    const char* d = a + 32 * PA;
+    if constexpr (SZ == 2) {
+      // transposed reads: lane supplies row (4*q4 + (r16>>2)) [+16], columns 4*(r16&3).. of its 16-column block
+      const int mrow = 4 * q4 + (r16 >> 2), pc = (r16 & 3) * 4;
+      bf16x8 af[KT], df[CT];
+#pragma unroll
+      for (int i = 0; i < KT; ++i) {
+        const char* p = a + mrow * PA + (((wk * KT + i) * 16 + pc) << 1);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 16 * PA));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        af[i] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const char* p = d + mrow * PD + (((wc * CT + j) * 16 + pc) << 1);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 16 * PD));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        df[j] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int i = 0; i < KT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], df[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int m = 4 * st + q4;
+        float af[KT], df[CT];
+#pragma unroll
+        for (int i = 0; i < KT; ++i) af[i] = *reinterpret_cast<const float*>(a + m * PA + (((wk * KT + i) * 16 + r16) << 2));
+#pragma unroll
+        for (int j = 0; j < CT; ++j) df[j] = *reinterpret_cast<const float*>(d + m * PD + (((wc * CT + j) * 16 + r16) << 2));
+#pragma unroll
+        for (int i = 0; i < KT; ++i)
+#pragma unroll
+          for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], df[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nst) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* slab = P.ws + ((int64_t)blockIdx.z * P.kpad_w + kblock * 128) * P.cn_pad + col0;
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = (wk * KT + i) * 16 + 4 * q4 + e, col = (wc * CT + j) * 16 + r16;
+        slab[(int64_t)row * P.cn_pad + col] = acc[i][j][e];
+      }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int nslabs, int kpad_w, int cn_pad, int A, int AS, int T,
+                                    int col0, int nb, float* __restrict__ dw, float* __restrict__ db) {
+  // one thread per (k, b): consecutive threads walk b (contiguous in the slab)
+  const int64_t total = (int64_t)(T * AS + 1) * nb;
+  const int64_t slab = (int64_t)kpad_w * cn_pad;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i / nb), b = (int)(i - (int64_t)k * nb);
+    const float* p = ws + (int64_t)k * cn_pad + col0 + b;
+    float s = 0.f;
+    for (int q = 0; q < nslabs; ++q) s += p[q * slab];
+    if (k == T * AS) {
+      if (db != nullptr) db[b] = s;
+    } else {
+      const int t = k / AS, a = k - t * AS;
+      if (a < A) dw[((int64_t)b * A + a) * T + t] = s;
+    }
+  }
+}
+
+template <typename T> static void launch_wgrad(const WgradKArgs& a, hipStream_t st) {
+  const int bnw = ctseg_wgrad_tile_cols(a.Cn);
+  dim3 grid((unsigned)(a.kpad_w / 128), (unsigned)(a.cn_pad / bnw), (unsigned)(a.N * a.splits));
+  if (bnw == 16) hipLaunchKernelGGL((conv_wgrad_kernel<T, 16, 4, 1>), grid, dim3(256), 0, st, a);
+  else if (bnw == 32) hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 2, 2>), grid, dim3(256), 0, st, a);
+  else if (bnw == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 2, 2>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 2, 2>), grid, dim3(256), 0, st, a);
+}
+
+}  // namespace ctseg
+
+using namespace ctseg;
+
+extern "C" int ctseg_wgrad_tile_cols(int32_t Cn) { return Cn <= 16 ? 16 : Cn <= 32 ? 32 : Cn <= 64 ? 64 : 128; }
+
+extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
+  CTSEG_REQUIRE(d != nullptr && d->in && d->dy && d->ws, "conv_wgrad: null pointer");
+  CTSEG_REQUIRE(d->dtype == CTSEG_F32 || d->dtype == CTSEG_BF16, "conv_wgrad: bad dtype");
+  const int SZ = d->dtype == CTSEG_F32 ? 4 : 2, EPC = 16 / SZ;
+  CTSEG_REQUIRE(d->Cg % EPC == 0 && d->g_ld % EPC == 0 && d->d_ld % EPC == 0, "conv_wgrad: channels must be 16-byte chunked");
+  CTSEG_REQUIRE(((uintptr_t)d->in % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "conv_wgrad: unaligned operand");
+  CTSEG_REQUIRE(d->ntaps >= 1 && d->ntaps <= CTSEG_MAX_TAPS && d->splits >= 1, "conv_wgrad: ntaps/splits");
+  const int bnw = ctseg_wgrad_tile_cols(d->Cn);
+  const int ktot = d->ntaps * d->Cg;
+  CTSEG_REQUIRE(d->kpad_w % 128 == 0 && d->kpad_w >= ktot + 1, "conv_wgrad: kpad_w %d (K=%d)", d->kpad_w, ktot);
+  CTSEG_REQUIRE(d->cn_pad % bnw == 0 && d->cn_pad >= d->Cn, "conv_wgrad: cn_pad %d", d->cn_pad);
+  WgradKArgs a;
+  a.in = (const char*)d->in; a.dy = (const char*)d->dy; a.ws = d->ws;
+  a.N = d->N; a.Xi = d->Xi; a.Yi = d->Yi; a.Zi = d->Zi; a.Xr = d->Xr; a.Yr = d->Yr; a.Zr = d->Zr;
+  a.Cg = d->Cg; a.Cn = d->Cn; a.g_ld = d->g_ld; a.d_ld = d->d_ld; a.sin = d->sin; a.ntaps = d->ntaps;
+  const int64_t rows64 = (int64_t)d->Xr * d->Yr * d->Zr;
+  CTSEG_REQUIRE(rows64 < (1ll << 31) - 4096, "conv_wgrad: row grid too large");
+  a.rows = (int)rows64; a.splits = d->splits;
+  int rps = (int)((rows64 + d->splits - 1) / d->splits);
+  rps = ((rps + 31) / 32) * 32;
+  a.rows_per_split = rps;
+  a.kpad_w = d->kpad_w; a.cn_pad = d->cn_pad;
+  int dv = ((d->Cn + EPC - 1) / EPC) * EPC;
+  a.d_valid = dv < d->d_ld ? dv : d->d_ld;
+  int step = 32;
+  a.sz = step % d->Zr; step /= d->Zr;
+  a.sy = step % d->Yr; a.sx = step / d->Yr;
+  for (int i = 0; i < CTSEG_MAX_TAPS; ++i) a.taps[i] = i < d->ntaps ? d->taps[i] : 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == CTSEG_F32) launch_wgrad<float>(a, st);
+  else launch_wgrad<BF16>(a, st);
+  CTSEG_LAUNCH_CHECK("conv_wgrad");
+  return 0;
+}
+
+extern "C" int ctseg_conv_wgrad_reduce(const float* ws, int32_t nslabs, int32_t kpad_w, int32_t cn_pad, int32_t A, int32_t AS,
+                                       int32_t T, int32_t col0, int32_t nb, float* dw, float* db, void* stream) {
+  CTSEG_REQUIRE(ws && dw && nslabs >= 1 && A <= AS && T * AS + 1 <= kpad_w && col0 + nb <= cn_pad, "wgrad_reduce: bad arguments");
+  const int64_t total = (int64_t)(T * AS + 1) * nb;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws, nslabs, kpad_w, cn_pad, A, AS, T,
+                     col0, nb, dw, db);
+  CTSEG_LAUNCH_CHECK("wgrad_reduce");
+  return 0;
+}

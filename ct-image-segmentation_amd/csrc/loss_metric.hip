@@ -1,0 +1,307 @@
+// Loss / metric kernels for the reference's 3-D training step (gfx950, HBM-bound, one voxel per lane):
+//   ctseg_squash_masks  : _squash_masks_3D (capstone/volumetric/utils.py:4-7)
+//   ctseg_seg_loss      : F.cross_entropy [+ class weights] (capstone/models/losses.py:45-68), softmax -> argmax
+//                         (capstone/training/utils.py:19-20), the integer counts behind compute_meandice
+//                         (capstone/models/temp.py:173-214), soft-Dice / focal sums (monai DiceLoss, FocalLoss as
+//                         configured at capstone/volumetric/losses.py:72-77,107) and d(loss)/d(logits).
+// The reference materialises softmax, two 1 GB one-hots and their product; here one pass reads the logits
+// once, keeps everything in registers and reduces with wave shuffles -> per-workgroup fp64 partials
+// (summed later in fixed order: deterministic) and exact int64 counts.
+#include "ctseg_dev.h"
+
+namespace ctseg {
+
+constexpr int CMAX = 16;
+
+__global__ __launch_bounds__(256) void squash_masks_kernel(const uint8_t* __restrict__ masks, int K, int64_t S,
+                                                           uint8_t* __restrict__ labels, int64_t* __restrict__ labels_i64,
+                                                           unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int s_h[32];
+  const int b = blockIdx.y;
+  if (threadIdx.x < 32) s_h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint8_t* mb = masks + (int64_t)b * K * S;
+  const bool vec = (S % 16 == 0) && (((uintptr_t)masks % 16) == 0) && (((uintptr_t)labels % 16) == 0);
+  const int64_t nchunk = (S + 15) / 16;
+  for (int64_t ch = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ch < nchunk; ch += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v0 = ch * 16;
+    int lab[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lab[i] = 0;
+    if (vec) {
+      for (int k = 0; k < K; ++k) {
+        const u32x4 m = *reinterpret_cast<const u32x4*>(mb + (int64_t)k * S + v0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int val = (int)((m[i >> 2] >> (8 * (i & 3))) & 0xffu) * (k + 1);
+          lab[i] = val > lab[i] ? val : lab[i];
+        }
+      }
+      u32x4 o;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        o[w] = (uint32_t)(lab[4 * w] & 0xff) | ((uint32_t)(lab[4 * w + 1] & 0xff) << 8) | ((uint32_t)(lab[4 * w + 2] & 0xff) << 16) |
+               ((uint32_t)(lab[4 * w + 3] & 0xff) << 24);
+      *reinterpret_cast<u32x4*>(labels + (int64_t)b * S + v0) = o;
+    } else {
+      for (int i = 0; i < 16; ++i) {
+        if (v0 + i >= S) break;
+        int l = 0;
+        for (int k = 0; k < K; ++k) {
+          const int val = (int)mb[(int64_t)k * S + v0 + i] * (k + 1);
+          l = val > l ? val : l;
+        }
+        lab[i] = l;
+        labels[(int64_t)b * S + v0 + i] = (uint8_t)l;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (v0 + i < S) {
+        if (labels_i64 != nullptr) labels_i64[(int64_t)b * S + v0 + i] = lab[i];
+        if (lab[i] <= K) atomicAdd(&s_h[lab[i]], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x <= K && hist != nullptr && s_h[threadIdx.x] != 0)
+    atomicAdd(&hist[(int64_t)b * (K + 1) + threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
+}
+
+// One pass over fp32 channels-last logits.  Block (p, b) covers voxels [p*vp, (p+1)*vp) of sample b.
+template <typename GT>
+__global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__ logits, int ld, const uint8_t* __restrict__ labels,
+                                                       int64_t S, int C, const float* __restrict__ class_weight, int do_stats,
+                                                       double* __restrict__ part, int P, unsigned long long* __restrict__ cnt,
+                                                       int do_grad, const float* __restrict__ coef, char* __restrict__ dlogits,
+                                                       int g_ld, uint8_t* __restrict__ pred_out) {
+  constexpr int GSZ = TT<GT>::SZ, GEPC = TT<GT>::EPC;
+  __shared__ float s_coef[1 + 3 * CMAX];
+  __shared__ float s_cw[CMAX];
+  __shared__ double s_part[4][2 + 3 * CMAX];
+  __shared__ unsigned int s_cnt[3 * CMAX];
+  const int p = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < CMAX) s_cw[tid] = (class_weight != nullptr && tid < C) ? class_weight[tid] : 1.f;
+  if (tid < 1 + 3 * CMAX) s_coef[tid] = 0.f;
+  if (tid < 3 * CMAX) s_cnt[tid] = 0u;
+  __syncthreads();
+  if (do_grad && tid < 1 + 3 * C) {
+    // coef[b] = (ce_scale, a[C], b[C], f[C]) -> padded to CMAX per table
+    const float v = coef[(int64_t)b * (1 + 3 * C) + tid];
+    if (tid == 0) s_coef[0] = v;
+    else { const int t = (tid - 1) / C, c = (tid - 1) % C; s_coef[1 + t * CMAX + c] = v; }
+  }
+  __syncthreads();
+  const int64_t vp = (S + P - 1) / P;
+  const int64_t v0 = p * vp, v1 = (v0 + vp < S) ? v0 + vp : S;
+  const int nld4 = ld / 4;
+
+  float a_ce = 0.f, a_w = 0.f;
+  float a_p[CMAX], a_py[CMAX], a_fo[CMAX];
+  unsigned int c_in[CMAX], c_pr[CMAX], c_tr[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) { a_p[c] = a_py[c] = a_fo[c] = 0.f; c_in[c] = c_pr[c] = c_tr[c] = 0u; }
+
+  for (int64_t v = v0 + tid; v < v1; v += 256) {
+    const int64_t vox = (int64_t)b * S + v;
+    float x[CMAX];
+    const f32x4* lp = reinterpret_cast<const f32x4*>(logits + vox * ld);
+#pragma unroll
+    for (int q = 0; q < CMAX / 4; ++q) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (q < nld4) t = lp[q];
+      x[4 * q] = t[0]; x[4 * q + 1] = t[1]; x[4 * q + 2] = t[2]; x[4 * q + 3] = t[3];
+    }
+    const int t = (int)labels[vox];
+    float m = x[0];
+#pragma unroll
+    for (int c = 1; c < CMAX; ++c) if (c < C) m = fmaxf(m, x[c]);
+    float e[CMAX], ssum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { e[c] = (c < C) ? expf(x[c] - m) : 0.f; if (c < C) ssum += e[c]; }
+    // softmax THEN argmax, first maximal index (capstone/training/utils.py:19-20)
+    float pr[CMAX], best = -1.f;
+    int pred = 0;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      pr[c] = (c < C) ? e[c] / ssum : 0.f;
+      if (c < C && pr[c] > best) { best = pr[c]; pred = c; }
+    }
+    const float lse = m + logf(ssum);
+    float xt = 0.f, pt = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) if (c == t) { xt = x[c]; pt = pr[c]; }
+    const float logpt = xt - lse;
+    const float w = s_cw[t < CMAX ? t : 0];
+    if (pred_out != nullptr) pred_out[vox] = (uint8_t)pred;
+    if (do_stats) {
+      a_ce += w * (lse - xt);
+      a_w += w;
+      const float om = 1.f - pt;
+      const float fo = -om * om * logpt;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) {
+        if (c < C) {
+          a_p[c] += pr[c];
+          if (c == t) { a_py[c] += pr[c]; a_fo[c] += fo; c_tr[c] += 1u; }
+          if (c == pred) { c_pr[c] += 1u; if (c == t) c_in[c] += 1u; }
+        }
+      }
+    }
+    if (do_grad) {
+      const float ce_scale = s_coef[0] * w;
+      // soft-Dice: dL/dp_c = a_c*[c==t] + b_c ; through softmax: p_k (g_k - sum_j g_j p_j)
+      float gk[CMAX], dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) {
+        gk[c] = (c < C) ? (s_coef[1 + CMAX + c] + (c == t ? s_coef[1 + c] : 0.f)) : 0.f;
+        dot += gk[c] * pr[c];
+      }
+      const float ft = s_coef[1 + 2 * CMAX + (t < CMAX ? t : 0)];
+      const float om = 1.f - pt;
+      const float fterm = ft * (2.f * om * pt * logpt - om * om);
+      float d[CMAX];
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) {
+        const float ind = (c == t) ? 1.f : 0.f;
+        d[c] = (c < C) ? (ce_scale * (pr[c] - ind) + pr[c] * (gk[c] - dot) + fterm * (ind - pr[c])) : 0.f;
+      }
+      char* gp = dlogits + vox * g_ld * GSZ;
+#pragma unroll
+      for (int q = 0; q < CMAX / GEPC; ++q)
+        if (q * GEPC < g_ld) store_chunk<GT>(gp + q * 16, d + q * GEPC);
+    }
+  }
+
+  if (do_stats) {
+    // wave shuffle reduction (fp64) -> LDS -> one partial record per workgroup
+    double rec[2 + 3 * CMAX];
+    rec[0] = a_ce; rec[1] = a_w;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { rec[2 + c] = a_p[c]; rec[2 + CMAX + c] = a_py[c]; rec[2 + 2 * CMAX + c] = a_fo[c]; }
+#pragma unroll
+    for (int i = 0; i < 2 + 3 * CMAX; ++i) {
+      const double s = wave_sum(rec[i]);
+      if (lane == 0) s_part[wave][i] = s;
+    }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      unsigned int a = c_in[c], bq = c_pr[c], cq = c_tr[c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); bq += __shfl_xor(bq, o, 64); cq += __shfl_xor(cq, o, 64); }
+      if (lane == 0 && c < C) {
+        if (a) atomicAdd(&s_cnt[c], a);
+        if (bq) atomicAdd(&s_cnt[CMAX + c], bq);
+        if (cq) atomicAdd(&s_cnt[2 * CMAX + c], cq);
+      }
+    }
+    __syncthreads();
+    const int R = 2 + 3 * C;
+    if (tid < R) {
+      int src = tid;
+      if (tid >= 2) { const int t = (tid - 2) / C, c = (tid - 2) % C; src = 2 + t * CMAX + c; }
+      const double s = s_part[0][src] + s_part[1][src] + s_part[2][src] + s_part[3][src];
+      part[((int64_t)b * P + p) * R + tid] = s;
+    }
+    if (tid < 3 * C) {
+      const int t = tid / C, c = tid % C;
+      const unsigned int v = s_cnt[t * CMAX + c];
+      if (v) atomicAdd(&cnt[((int64_t)b * 3 + t) * C + c], (unsigned long long)v);
+    }
+  }
+}
+
+// Dice counts from two label maps (DiceMetricWrapper called on already-squashed predictions)
+__global__ __launch_bounds__(256) void dice_counts_kernel(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ truth,
+                                                          int64_t S, int C, unsigned long long* __restrict__ cnt) {
+  __shared__ unsigned int s_cnt[3 * CMAX];
+  const int b = blockIdx.y;
+  if (threadIdx.x < 3 * CMAX) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < S; v += (int64_t)gridDim.x * blockDim.x) {
+    const int p = pred[(int64_t)b * S + v], t = truth[(int64_t)b * S + v];
+    if (p < C) atomicAdd(&s_cnt[CMAX + p], 1u);
+    if (t < C) atomicAdd(&s_cnt[2 * CMAX + t], 1u);
+    if (p == t && p < C) atomicAdd(&s_cnt[p], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 * C) {
+    const int k = threadIdx.x / C, c = threadIdx.x % C;
+    const unsigned int v = s_cnt[k * CMAX + c];
+    if (v) atomicAdd(&cnt[((int64_t)b * 3 + k) * C + c], (unsigned long long)v);
+  }
+}
+
+// part [B][P][R] -> out [B][R]; 1024 threads: 16 strided sub-sums per record entry, combined in fixed order
+__global__ __launch_bounds__(1024) void reduce_partials_f64_kernel(const double* __restrict__ part, int P, int R,
+                                                                   double* __restrict__ out) {
+  __shared__ double s[16][64];
+  const int b = blockIdx.x, r = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  double a = 0.0;
+  if (r < R)
+    for (int p = sub; p < P; p += 16) a += part[((int64_t)b * P + p) * R + r];
+  s[sub][r] = a;
+  __syncthreads();
+  if (sub == 0 && r < R) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += s[i][r];
+    out[(int64_t)b * R + r] = t;
+  }
+}
+
+}  // namespace ctseg
+
+using namespace ctseg;
+
+extern "C" int ctseg_squash_masks(const uint8_t* masks, int32_t B, int32_t K, int64_t S, uint8_t* labels, int64_t* labels_i64,
+                                  int64_t* hist, void* stream) {
+  CTSEG_REQUIRE(masks && labels && B > 0 && K > 0 && K < 32 && S > 0, "squash_masks: bad arguments");
+  const int64_t nchunk = (S + 15) / 16;
+  int64_t blocks = (nchunk + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(squash_masks_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, masks, K, S, labels,
+                     labels_i64, (unsigned long long*)hist);
+  CTSEG_LAUNCH_CHECK("squash_masks");
+  return 0;
+}
+
+extern "C" int ctseg_seg_loss(const float* logits, int32_t ld, const uint8_t* labels, int32_t B, int64_t S, int32_t C,
+                              const float* class_weight, int32_t do_stats, double* part, int32_t P, int64_t* cnt,
+                              int32_t do_grad, const float* coef, void* dlogits, int32_t g_ld, int32_t gdtype, uint8_t* pred_out,
+                              void* stream) {
+  CTSEG_REQUIRE(logits && labels && B > 0 && S > 0 && C >= 2 && C <= CMAX, "seg_loss: bad arguments (C <= 16)");
+  CTSEG_REQUIRE(ld % 4 == 0 && ld >= C && ld <= CMAX && ((uintptr_t)logits % 16) == 0, "seg_loss: logits stride %d", ld);
+  CTSEG_REQUIRE(P > 0 && (!do_stats || (part && cnt)), "seg_loss: stats buffers");
+  if (do_grad) {
+    CTSEG_REQUIRE(coef && dlogits && (gdtype == CTSEG_F32 || gdtype == CTSEG_BF16), "seg_loss: grad buffers");
+    const int gepc = gdtype == CTSEG_F32 ? 4 : 8;
+    CTSEG_REQUIRE(g_ld % gepc == 0 && g_ld >= C && g_ld <= CMAX && ((uintptr_t)dlogits % 16) == 0, "seg_loss: dlogits stride %d", g_ld);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (do_grad && gdtype == CTSEG_BF16)
+    hipLaunchKernelGGL(seg_loss_kernel<BF16>, dim3(P, B), dim3(256), 0, st, logits, ld, labels, S, C, class_weight, do_stats, part,
+                       P, (unsigned long long*)cnt, do_grad, coef, (char*)dlogits, g_ld, pred_out);
+  else
+    hipLaunchKernelGGL(seg_loss_kernel<float>, dim3(P, B), dim3(256), 0, st, logits, ld, labels, S, C, class_weight, do_stats, part,
+                       P, (unsigned long long*)cnt, do_grad, coef, (char*)dlogits, g_ld, pred_out);
+  CTSEG_LAUNCH_CHECK("seg_loss");
+  return 0;
+}
+
+extern "C" int ctseg_reduce_partials_f64(const double* part, int32_t B, int32_t P, int32_t R, double* out, void* stream) {
+  CTSEG_REQUIRE(part && out && B > 0 && P > 0 && R > 0 && R <= 64, "reduce_partials_f64: bad arguments");
+  hipLaunchKernelGGL(reduce_partials_f64_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, part, P, R, out);
+  CTSEG_LAUNCH_CHECK("reduce_partials_f64");
+  return 0;
+}
+
+extern "C" int ctseg_dice_counts(const uint8_t* pred, const uint8_t* truth, int32_t B, int64_t S, int32_t C, int64_t* cnt,
+                                 void* stream) {
+  CTSEG_REQUIRE(pred && truth && cnt && B > 0 && S > 0 && C >= 2 && C <= CMAX, "dice_counts: bad arguments");
+  int64_t blocks = (S + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(dice_counts_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, pred, truth, S, C,
+                     (unsigned long long*)cnt);
+  CTSEG_LAUNCH_CHECK("dice_counts");
+  return 0;
+}

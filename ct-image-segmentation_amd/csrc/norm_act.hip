@@ -1,0 +1,354 @@
+// InstanceNorm3d(affine=False) + PReLU forward/backward for channels-last activations (gfx950).
+// MONAI's Convolution block = conv -> InstanceNorm -> PReLU; the reference reaches it
+// through UNet.forward (capstone/volumetric/base_trainer.py:74-78) and autograd.
+//
+// Statistics arrive as per-tile (sum, sumsq) partials from the conv epilogue and are combined in
+// fp64 in a fixed order (deterministic).  All passes are HBM-bound: 16-byte vector accesses,
+// per-sample mean/rstd staged in LDS, wave/LDS reductions for the backward sums.
+#include "ctseg_dev.h"
+
+namespace ctseg {
+
+constexpr int FIN_GROUPS = 64;
+
+// level 1: partials [N][P][R*ld] fp32 -> scratch [N][64][R*ld] fp64 (group g sums tiles g*F .. g*F+F-1 in order)
+__global__ void partial_l1_kernel(const float* __restrict__ part, int P, int rowlen, double* __restrict__ scratch) {
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int F = (P + FIN_GROUPS - 1) / FIN_GROUPS;
+  const int p0 = g * F, p1 = (p0 + F < P) ? p0 + F : P;
+  for (int j = threadIdx.x; j < rowlen; j += blockDim.x) {
+    double s = 0.0;
+    for (int p = p0; p < p1; ++p) s += (double)part[((int64_t)n * P + p) * rowlen + j];
+    scratch[((int64_t)n * FIN_GROUPS + g) * rowlen + j] = s;
+  }
+}
+
+__global__ void instnorm_l2_kernel(const double* __restrict__ scratch, int ld, int col0, int C, double count, double eps,
+                                   float* __restrict__ mean_rstd) {
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s = 0.0, q = 0.0;
+    for (int g = 0; g < FIN_GROUPS; ++g) {
+      s += scratch[((int64_t)n * FIN_GROUPS + g) * 2 * ld + col0 + c];
+      q += scratch[((int64_t)n * FIN_GROUPS + g) * 2 * ld + ld + col0 + c];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_rstd[((int64_t)n * C + c) * 2] = (float)mean;
+    mean_rstd[((int64_t)n * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + eps));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_prelu_fwd_kernel(const char* __restrict__ y, int y_ld,
+                                                                  const float* __restrict__ mean_rstd,
+                                                                  const float* __restrict__ alpha, const char* __restrict__ res,
+                                                                  int res_ld, char* __restrict__ out, int out_ld, int64_t S,
+                                                                  int C, int Cv) {
+  constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
+  extern __shared__ float s_mr[];  // [C][2]
+  const int n = blockIdx.y;
+  if (mean_rstd != nullptr)
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_mr[i] = mean_rstd[(int64_t)n * C * 2 + i];
+  __syncthreads();
+  const float al = alpha != nullptr ? alpha[0] : 1.f;
+  const int64_t total = S * Cv;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / Cv;
+    const int cv = (int)(i - v * Cv);
+    const int64_t vox = (int64_t)n * S + v;
+    float x[EPC], r[EPC];
+    load_chunk<T>(y + (vox * y_ld + cv * EPC) * SZ, x);
+    if (res != nullptr) load_chunk<T>(res + (vox * res_ld + cv * EPC) * SZ, r);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int c = cv * EPC + e;
+      float o = 0.f;
+      if (c < C) {
+        o = x[e];
+        if (mean_rstd != nullptr) {
+          o = (o - s_mr[2 * c]) * s_mr[2 * c + 1];
+          o = o > 0.f ? o : al * o;
+        }
+        if (res != nullptr) o += r[e];
+      }
+      x[e] = o;
+    }
+    store_chunk<T>(out + (vox * out_ld + cv * EPC) * SZ, x);
+  }
+}
+
+// backward pass 1: per block (p, n): rows [p*rows_per, ...) of sample n -> partials[n][p][3][ld]
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_prelu_bwd_reduce_kernel(const char* __restrict__ g, int g_ld,
+                                                                         const char* __restrict__ y, int y_ld,
+                                                                         const float* __restrict__ mean_rstd,
+                                                                         const float* __restrict__ alpha,
+                                                                         float* __restrict__ partials, int P, int ld, int64_t S,
+                                                                         int C, int Cv) {
+  constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
+  __shared__ float s_red[256 * 3 * EPC];
+  extern __shared__ float s_mr[];
+  const int p = blockIdx.x, n = blockIdx.y;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_mr[i] = mean_rstd[(int64_t)n * C * 2 + i];
+  __syncthreads();
+  const float al = alpha[0];
+  const int64_t rows_per = (S + P - 1) / P;
+  const int64_t v0 = p * rows_per, v1 = (v0 + rows_per < S) ? v0 + rows_per : S;
+  const int nrow_thr = 256 / Cv;  // threads along rows
+  const int cv = threadIdx.x % Cv, rsub = threadIdx.x / Cv;
+  float a1[EPC], a2[EPC], a3[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) a1[e] = a2[e] = a3[e] = 0.f;
+  if (rsub < nrow_thr) {
+    for (int64_t v = v0 + rsub; v < v1; v += nrow_thr) {
+      const int64_t vox = (int64_t)n * S + v;
+      float gv[EPC], yv[EPC];
+      load_chunk<T>(g + (vox * g_ld + cv * EPC) * SZ, gv);
+      load_chunk<T>(y + (vox * y_ld + cv * EPC) * SZ, yv);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int c = cv * EPC + e;
+        if (c < C) {
+          const float xh = (yv[e] - s_mr[2 * c]) * s_mr[2 * c + 1];
+          const float dxh = gv[e] * (xh > 0.f ? 1.f : al);
+          a1[e] += dxh;
+          a2[e] += dxh * xh;
+          a3[e] += xh > 0.f ? 0.f : gv[e] * xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    s_red[(threadIdx.x * 3 + 0) * EPC + e] = a1[e];
+    s_red[(threadIdx.x * 3 + 1) * EPC + e] = a2[e];
+    s_red[(threadIdx.x * 3 + 2) * EPC + e] = a3[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
+    const int which = i / C, c = i - which * C;
+    const int ccv = c / EPC, e = c - ccv * EPC;
+    float s = 0.f;
+    for (int r = 0; r < nrow_thr; ++r) s += s_red[((r * Cv + ccv) * 3 + which) * EPC + e];
+    partials[(((int64_t)n * P + p) * 3 + which) * ld + c] = s;
+  }
+}
+
+__global__ void instnorm_prelu_bwd_finalize_kernel(const float* __restrict__ partials, int N, int P, int ld, int C, double S,
+                                                   float* __restrict__ sums, float* __restrict__ dalpha) {
+  __shared__ double s_da[256];
+  double da = 0.0;
+  for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+    const int n = i / C, c = i - n * C;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int p = 0; p < P; ++p) {
+      const float* q = partials + ((int64_t)n * P + p) * 3 * ld + c;
+      s1 += (double)q[0];
+      s2 += (double)q[ld];
+      s3 += (double)q[2 * ld];
+    }
+    sums[(int64_t)i * 2] = (float)(s1 / S);
+    sums[(int64_t)i * 2 + 1] = (float)(s2 / S);
+    da += s3;
+  }
+  s_da[threadIdx.x] = da;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < (int)blockDim.x; ++i) t += s_da[i];
+    dalpha[0] = (float)t;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const char* __restrict__ g, int g_ld,
+                                                                        const char* __restrict__ y, int y_ld,
+                                                                        const float* __restrict__ mean_rstd,
+                                                                        const float* __restrict__ alpha,
+                                                                        const float* __restrict__ sums, char* __restrict__ dy,
+                                                                        int dy_ld, char* __restrict__ g_copy, int g_copy_ld,
+                                                                        int64_t S, int C, int Cv) {
+  constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
+  extern __shared__ float s_tab[];  // [C][4]: mean, rstd, s1, s2
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    s_tab[4 * i] = mean_rstd[((int64_t)n * C + i) * 2];
+    s_tab[4 * i + 1] = mean_rstd[((int64_t)n * C + i) * 2 + 1];
+    s_tab[4 * i + 2] = sums[((int64_t)n * C + i) * 2];
+    s_tab[4 * i + 3] = sums[((int64_t)n * C + i) * 2 + 1];
+  }
+  __syncthreads();
+  const float al = alpha[0];
+  const int64_t total = S * Cv;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / Cv;
+    const int cv = (int)(i - v * Cv);
+    const int64_t vox = (int64_t)n * S + v;
+    float gv[EPC], yv[EPC], o[EPC];
+    load_chunk<T>(g + (vox * g_ld + cv * EPC) * SZ, gv);
+    load_chunk<T>(y + (vox * y_ld + cv * EPC) * SZ, yv);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int c = cv * EPC + e;
+      float r = 0.f;
+      if (c < C) {
+        const float rstd = s_tab[4 * c + 1];
+        const float xh = (yv[e] - s_tab[4 * c]) * rstd;
+        const float dxh = gv[e] * (xh > 0.f ? 1.f : al);
+        r = rstd * (dxh - s_tab[4 * c + 2] - xh * s_tab[4 * c + 3]);
+      }
+      o[e] = r;
+    }
+    store_chunk<T>(dy + (vox * dy_ld + cv * EPC) * SZ, o);
+    if (g_copy != nullptr) store_chunk<T>(g_copy + (vox * g_copy_ld + cv * EPC) * SZ, gv);
+  }
+}
+
+// column sums of a channels-last tensor over all rows (ConvTranspose bias gradient): partials [P][ld] then fixed-order sum
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const char* __restrict__ x, int ld, int64_t rows, int C, int Cv,
+                                                             float* __restrict__ partials, int P, int pld) {
+  constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
+  __shared__ float s_red[256 * EPC];
+  const int p = blockIdx.x;
+  const int64_t rows_per = (rows + P - 1) / P;
+  const int64_t v0 = p * rows_per, v1 = (v0 + rows_per < rows) ? v0 + rows_per : rows;
+  const int nrow_thr = 256 / Cv, cv = threadIdx.x % Cv, rsub = threadIdx.x / Cv;
+  float a[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) a[e] = 0.f;
+  if (rsub < nrow_thr)
+    for (int64_t v = v0 + rsub; v < v1; v += nrow_thr) {
+      float xv[EPC];
+      load_chunk<T>(x + (v * ld + cv * EPC) * SZ, xv);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) a[e] += xv[e];
+    }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) s_red[threadIdx.x * EPC + e] = a[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < nrow_thr; ++r) s += s_red[(r * Cv + c / EPC) * EPC + (c % EPC)];
+    partials[(int64_t)p * pld + c] = s;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partials, int P, int pld, int C, float* __restrict__ out) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s += (double)partials[(int64_t)p * pld + c];
+    out[c] = (float)s;
+  }
+}
+
+static inline int ew_blocks(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace ctseg
+
+using namespace ctseg;
+
+#define CHECK_CL(dtype, C, ...)                                                                            \
+  CTSEG_REQUIRE(dtype == CTSEG_F32 || dtype == CTSEG_BF16, "bad dtype");                                   \
+  const int EPC_ = dtype == CTSEG_F32 ? 4 : 8;                                                             \
+  const int Cv = (C + EPC_ - 1) / EPC_;                                                                    \
+  {                                                                                                        \
+    const int lds_[] = {__VA_ARGS__};                                                                      \
+    for (int ld_ : lds_) CTSEG_REQUIRE(ld_ % EPC_ == 0 && ld_ >= Cv * EPC_, "channel stride %d not chunked for C=%d", ld_, C); \
+  }
+
+extern "C" int ctseg_instnorm_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t col0, int32_t C,
+                                       double count, double eps, double* scratch, float* mean_rstd, void* stream) {
+  CTSEG_REQUIRE(partials && scratch && mean_rstd && N > 0 && P > 0 && C > 0 && col0 >= 0 && col0 + C <= ld,
+                "instnorm_finalize: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(partial_l1_kernel, dim3(FIN_GROUPS, N), dim3(256), 0, st, partials, P, 2 * ld, scratch);
+  hipLaunchKernelGGL(instnorm_l2_kernel, dim3(N), dim3(256), 0, st, scratch, ld, col0, C, count, eps, mean_rstd);
+  CTSEG_LAUNCH_CHECK("instnorm_finalize");
+  return 0;
+}
+
+extern "C" int ctseg_instnorm_prelu_fwd(int32_t dtype, const void* y, int32_t y_ld, const float* mean_rstd, const float* alpha,
+                                        const void* res, int32_t res_ld, void* out, int32_t out_ld, int32_t N, int64_t S,
+                                        int32_t C, void* stream) {
+  CTSEG_REQUIRE(y && out && N > 0 && S > 0 && C > 0, "instnorm_prelu_fwd: bad arguments");
+  CHECK_CL(dtype, C, y_ld, out_ld, res ? res_ld : y_ld);
+  CTSEG_REQUIRE(mean_rstd == nullptr || alpha != nullptr, "instnorm_prelu_fwd: alpha missing");
+  dim3 grid(ew_blocks(S * Cv), N);
+  const size_t sh = 2 * C * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CTSEG_F32)
+    hipLaunchKernelGGL(instnorm_prelu_fwd_kernel<float>, grid, dim3(256), sh, st, (const char*)y, y_ld, mean_rstd, alpha,
+                       (const char*)res, res_ld, (char*)out, out_ld, S, C, Cv);
+  else
+    hipLaunchKernelGGL(instnorm_prelu_fwd_kernel<BF16>, grid, dim3(256), sh, st, (const char*)y, y_ld, mean_rstd, alpha,
+                       (const char*)res, res_ld, (char*)out, out_ld, S, C, Cv);
+  CTSEG_LAUNCH_CHECK("instnorm_prelu_fwd");
+  return 0;
+}
+
+extern "C" int ctseg_instnorm_prelu_bwd_reduce(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
+                                               const float* mean_rstd, const float* alpha, float* partials, int32_t P,
+                                               int32_t ld, int32_t N, int64_t S, int32_t C, void* stream) {
+  CTSEG_REQUIRE(g && y && mean_rstd && alpha && partials && P > 0 && N > 0 && C <= ld, "instnorm_prelu_bwd_reduce: bad arguments");
+  CHECK_CL(dtype, C, g_ld, y_ld);
+  CTSEG_REQUIRE(Cv <= 256, "instnorm_prelu_bwd_reduce: too many channels");
+  const size_t sh = 2 * C * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CTSEG_F32)
+    hipLaunchKernelGGL(instnorm_prelu_bwd_reduce_kernel<float>, dim3(P, N), dim3(256), sh, st, (const char*)g, g_ld,
+                       (const char*)y, y_ld, mean_rstd, alpha, partials, P, ld, S, C, Cv);
+  else
+    hipLaunchKernelGGL(instnorm_prelu_bwd_reduce_kernel<BF16>, dim3(P, N), dim3(256), sh, st, (const char*)g, g_ld,
+                       (const char*)y, y_ld, mean_rstd, alpha, partials, P, ld, S, C, Cv);
+  CTSEG_LAUNCH_CHECK("instnorm_prelu_bwd_reduce");
+  return 0;
+}
+
+extern "C" int ctseg_instnorm_prelu_bwd_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t C, double S,
+                                                 float* sums, float* dalpha, void* stream) {
+  CTSEG_REQUIRE(partials && sums && dalpha && N > 0 && P > 0 && C > 0, "instnorm_prelu_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(instnorm_prelu_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, N, P, ld, C, S,
+                     sums, dalpha);
+  CTSEG_LAUNCH_CHECK("instnorm_prelu_bwd_finalize");
+  return 0;
+}
+
+extern "C" int ctseg_instnorm_prelu_bwd_apply(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
+                                              const float* mean_rstd, const float* alpha, const float* sums, void* dy,
+                                              int32_t dy_ld, void* g_copy, int32_t g_copy_ld, int32_t N, int64_t S, int32_t C,
+                                              void* stream) {
+  CTSEG_REQUIRE(g && y && mean_rstd && alpha && sums && dy && N > 0, "instnorm_prelu_bwd_apply: bad arguments");
+  CHECK_CL(dtype, C, g_ld, y_ld, dy_ld, g_copy ? g_copy_ld : dy_ld);
+  dim3 grid(ew_blocks(S * Cv), N);
+  const size_t sh = 4 * C * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CTSEG_F32)
+    hipLaunchKernelGGL(instnorm_prelu_bwd_apply_kernel<float>, grid, dim3(256), sh, st, (const char*)g, g_ld, (const char*)y,
+                       y_ld, mean_rstd, alpha, sums, (char*)dy, dy_ld, (char*)g_copy, g_copy_ld, S, C, Cv);
+  else
+    hipLaunchKernelGGL(instnorm_prelu_bwd_apply_kernel<BF16>, grid, dim3(256), sh, st, (const char*)g, g_ld, (const char*)y,
+                       y_ld, mean_rstd, alpha, sums, (char*)dy, dy_ld, (char*)g_copy, g_copy_ld, S, C, Cv);
+  CTSEG_LAUNCH_CHECK("instnorm_prelu_bwd_apply");
+  return 0;
+}
+
+extern "C" int ctseg_colsum(int32_t dtype, const void* x, int32_t ld, int64_t rows, int32_t C, float* partials, int32_t P,
+                            float* out, void* stream) {
+  CTSEG_REQUIRE(x && partials && out && rows > 0 && C > 0 && P > 0, "colsum: bad arguments");
+  CHECK_CL(dtype, C, ld);
+  CTSEG_REQUIRE(Cv <= 256, "colsum: too many channels");
+  const int pld = Cv * EPC_;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CTSEG_F32)
+    hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(P), dim3(256), 0, st, (const char*)x, ld, rows, C, Cv, partials, P, pld);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<BF16>, dim3(P), dim3(256), 0, st, (const char*)x, ld, rows, C, Cv, partials, P, pld);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, st, partials, P, pld, C, out);
+  CTSEG_LAUNCH_CHECK("colsum");
+  return 0;
+}

@@ -1,0 +1,157 @@
+// Adam step, weight packing, dtype / layout plumbing and the C-ABI error channel (gfx950).
+#include "ctseg_dev.h"
+
+namespace ctseg {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// torch.optim.Adam (amsgrad=False, weight_decay=0) as torch applies it:
+//   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                   float step_size, float bc2_sqrt, float gscale) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = gg[e] * gscale;
+      mm[e] = mm[e] + (gr - mm[e]) * (1.f - b1);  // torch: exp_avg.lerp_(grad, 1 - beta1)
+      vv[e] = vv[e] * b2 + (1.f - b2) * gr * gr;
+      const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+      pp[e] = pp[e] - step_size * (mm[e] / denom);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    const float gr = g[i] * gscale;
+    const float mm = m[i] + (gr - m[i]) * (1.f - b1);
+    const float vv = v[i] * b2 + (1.f - b2) * gr * gr;
+    m[i] = mm; v[i] = vv;
+    p[i] = p[i] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+  }
+}
+
+template <typename TD> __global__ void gather_cast_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                           TD* __restrict__ dst, int64_t n);
+template <typename TS, typename TD> __device__ __forceinline__ TD cvt(TS x);
+template <> __device__ __forceinline__ float cvt<float, float>(float x) { return x; }
+template <> __device__ __forceinline__ unsigned short cvt<float, unsigned short>(float x) { return (unsigned short)f2bf(x); }
+template <> __device__ __forceinline__ float cvt<unsigned short, float>(unsigned short x) { return bf2f(x); }
+template <> __device__ __forceinline__ unsigned short cvt<unsigned short, unsigned short>(unsigned short x) { return x; }
+
+template <typename TD> __global__ void gather_cast_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                           TD* __restrict__ dst, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = cvt<float, TD>(src[idx[i]]);
+}
+
+template <typename TS, typename TD> __global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = cvt<TS, TD>(s[i]);
+}
+
+// fp32 [N][C][S] -> [N][S][ld]; thread per (voxel, channel<ld): reads strided by S, writes contiguous (small C only)
+template <typename TD> __global__ void nc_to_cl_kernel(const float* __restrict__ s, TD* __restrict__ d, int C, int64_t S, int ld) {
+  const int n = blockIdx.y;
+  const int64_t total = S * ld;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / ld;
+    const int c = (int)(i - v * ld);
+    const float x = c < C ? s[((int64_t)n * C + c) * S + v] : 0.f;
+    d[(int64_t)n * total + i] = cvt<float, TD>(x);
+  }
+}
+template <typename TS> __global__ void cl_to_nc_kernel(const TS* __restrict__ s, float* __restrict__ d, int C, int64_t S, int ld) {
+  const int n = blockIdx.y;
+  const int64_t total = S * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i / S);
+    const int64_t v = i - (int64_t)c * S;
+    d[(int64_t)n * total + i] = cvt<TS, float>(s[((int64_t)n * S + v) * ld + c]);
+  }
+}
+
+static inline unsigned nblocks(int64_t total, int cap = 4096) {
+  int64_t b = (total + 255) / 256;
+  return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+}  // namespace ctseg
+
+using namespace ctseg;
+
+extern "C" int ctseg_abi_version(void) { return CTSEG_ABI_VERSION; }
+extern "C" const char* ctseg_last_error(void) { return g_err; }
+
+extern "C" int ctseg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, int32_t step, float grad_scale, void* stream) {
+  CTSEG_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+  CTSEG_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+                "adam_step: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n / 4 + 1, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                     beta2, eps, step_size, bc2_sqrt, grad_scale);
+  CTSEG_LAUNCH_CHECK("adam_step");
+  return 0;
+}
+
+extern "C" int ctseg_gather_cast(const float* src, const int32_t* idx, void* dst, int32_t dtype, int64_t n, void* stream) {
+  CTSEG_REQUIRE(src && idx && dst && n > 0 && (dtype == CTSEG_F32 || dtype == CTSEG_BF16), "gather_cast: bad arguments");
+  if (dtype == CTSEG_F32)
+    hipLaunchKernelGGL(gather_cast_kernel<float>, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, src, idx, (float*)dst, n);
+  else
+    hipLaunchKernelGGL(gather_cast_kernel<unsigned short>, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, src, idx,
+                       (unsigned short*)dst, n);
+  CTSEG_LAUNCH_CHECK("gather_cast");
+  return 0;
+}
+
+extern "C" int ctseg_cast(const void* src, int32_t sd, void* dst, int32_t dd, int64_t n, void* stream) {
+  CTSEG_REQUIRE(src && dst && n > 0, "cast: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nblocks(n)), blk(256);
+  if (sd == CTSEG_F32 && dd == CTSEG_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, unsigned short>), grid, blk, 0, st, (const float*)src, (unsigned short*)dst, n);
+  else if (sd == CTSEG_BF16 && dd == CTSEG_F32)
+    hipLaunchKernelGGL((cast_kernel<unsigned short, float>), grid, blk, 0, st, (const unsigned short*)src, (float*)dst, n);
+  else if (sd == CTSEG_F32 && dd == CTSEG_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), grid, blk, 0, st, (const float*)src, (float*)dst, n);
+  else if (sd == CTSEG_BF16 && dd == CTSEG_BF16)
+    hipLaunchKernelGGL((cast_kernel<unsigned short, unsigned short>), grid, blk, 0, st, (const unsigned short*)src,
+                       (unsigned short*)dst, n);
+  else CTSEG_REQUIRE(false, "cast: bad dtypes %d -> %d", sd, dd);
+  CTSEG_LAUNCH_CHECK("cast");
+  return 0;
+}
+
+extern "C" int ctseg_nc_to_cl(const float* src, void* dst, int32_t dtype, int32_t N, int32_t C, int64_t S, int32_t ld,
+                              void* stream) {
+  CTSEG_REQUIRE(src && dst && N > 0 && C > 0 && S > 0 && ld >= C, "nc_to_cl: bad arguments");
+  dim3 grid(nblocks(S * ld), N);
+  if (dtype == CTSEG_F32) hipLaunchKernelGGL(nc_to_cl_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, C, S, ld);
+  else hipLaunchKernelGGL(nc_to_cl_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, C, S, ld);
+  CTSEG_LAUNCH_CHECK("nc_to_cl");
+  return 0;
+}
+
+extern "C" int ctseg_cl_to_nc(const void* src, int32_t dtype, float* dst, int32_t N, int32_t C, int64_t S, int32_t ld,
+                              void* stream) {
+  CTSEG_REQUIRE(src && dst && N > 0 && C > 0 && S > 0 && ld >= C, "cl_to_nc: bad arguments");
+  dim3 grid(nblocks(S * C), N);
+  if (dtype == CTSEG_F32) hipLaunchKernelGGL(cl_to_nc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, C, S, ld);
+  else hipLaunchKernelGGL(cl_to_nc_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src, dst, C, S, ld);
+  CTSEG_LAUNCH_CHECK("cl_to_nc");
+  return 0;
+}

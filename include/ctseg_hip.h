@@ -1,0 +1,163 @@
+/*
+ * ctseg_hip.h — C ABI of libctseg_hip.so: the MI355X (gfx950) kernels behind the reference's
+ * 3-D U-Net training step.  Plain pointers and sizes only; no torch types.  Every pointer is a
+ * DEVICE pointer unless a parameter says "host".  `stream` is a hipStream_t passed as void*.
+ *
+ * The reference (MrinalJain17/CT-image-segmentation) has no FFI of its own: its hot path is Python
+ * calling torch/MONAI ops.  Each entry point below therefore names the reference call site (or the
+ * torch/MONAI op that call site executes) it replaces; INTEGRATION.md shows the ctypes binding.
+ *
+ * Layout convention: activations are channels-last, [N][X][Y][Z][ld] with `ld` >= C elements per
+ * voxel (X,Y,Z are the reference's (H,W,D) after ToTensorV3, capstone/volumetric/transforms.py:40;
+ * 2-D tensors use Z = 1).  dtype: CTSEG_F32 or CTSEG_BF16 storage, fp32 accumulation always.
+ *
+ * Return value: 0 on success, negative on a rejected argument or a HIP launch error
+ * (ctseg_last_error() gives the text).  Nothing here allocates, frees or synchronises.
+ */
+#ifndef CTSEG_HIP_H
+#define CTSEG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTSEG_ABI_VERSION 1
+#define CTSEG_F32 0
+#define CTSEG_BF16 1
+#define CTSEG_MAX_TAPS 27
+#define CTSEG_MAX_CLASSES 8
+
+int ctseg_abi_version(void);
+const char* ctseg_last_error(void);
+
+/* One output-parity class of an implicit-GEMM convolution pass.  A plain convolution has one class;
+ * a stride-2 transposed convolution (and the input-gradient of a stride-2 convolution) has 8. */
+typedef struct ctseg_conv_class {
+  int32_t ntaps;                 /* K = ntaps * Cg                                            */
+  int32_t kpad;                  /* padded K of this class's weight rows (multiple of 128 B)    */
+  int64_t w_off;                 /* element offset of this class's [rows][kpad] weight block    */
+  int32_t ox, oy, oz;            /* written voxel = row * sout + (ox,oy,oz)                     */
+  int32_t taps[CTSEG_MAX_TAPS];  /* packed offsets (dx&255)|(dy&255)<<8|(dz&255)<<16, int8 each */
+} ctseg_conv_class;
+
+/* Implicit-GEMM pass: out[row-voxel][n] = bias[n] + add[..][n] + sum_{tap,c} in[row*sin+d(tap)][c] * W[n][tap*Cg+c]
+ * Replaces nn.Conv3d / nn.ConvTranspose3d forward and input-gradient inside monai UNet
+ * (reference capstone/models/__init__.py:3, built at capstone/volumetric/base_trainer.py:65-72). */
+typedef struct ctseg_conv_desc {
+  const void* in;        /* gathered tensor [N][Xi][Yi][Zi][g_ld]                                */
+  const void* w;         /* packed weights (ctseg_pack_weights), rows padded to a multiple of 128 */
+  const float* bias;     /* [Cn] or NULL                                                         */
+  void* out;             /* written tensor [N][Xo][Yo][Zo][o_ld]                                  */
+  const void* add;       /* optional addend with out's voxel indexing, [..][add_ld]; may == out    */
+  float* stats;          /* optional per-tile (sum, sumsq) partials [N][stats_tiles][2][stats_ld]  */
+  int32_t dtype;         /* CTSEG_F32 / CTSEG_BF16: storage of in, w (and out/add unless *_f32)    */
+  int32_t N, Xi, Yi, Zi; /* gathered tensor dims                                                  */
+  int32_t Xr, Yr, Zr;    /* row grid per sample                                                   */
+  int32_t Xo, Yo, Zo;    /* written tensor dims                                                   */
+  int32_t Cg, Cn;        /* gathered channels per tap, GEMM columns                               */
+  int32_t Cn_store;      /* channels actually stored per voxel (>= Cn, pad columns are zeros)      */
+  int32_t g_ld, o_ld, add_ld;
+  int32_t sin, sout;
+  int32_t out_f32, add_f32;
+  int32_t stats_ld, stats_tiles, stats_tile0; /* partial layout; this call fills tiles [tile0, tile0+tiles*nclass) */
+  int32_t nclass;
+  ctseg_conv_class cls[CTSEG_MAX_CLASSES];
+} ctseg_conv_desc;
+
+/* Rows of the row grid / output columns one workgroup tile covers for a pass with Cn columns. */
+int ctseg_conv_tile_rows(int32_t Cn);
+int ctseg_conv_tile_cols(int32_t Cn);
+int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream);
+
+/* Weight gradient: R[tap*Cg+a][b] = sum_rows in[row*sin+d(tap)][a] * dy[row][b]; row K=ntaps*Cg of R is
+ * sum_rows dy[row][b] (the bias gradient).  Written as `splits` fp32 slabs [N*splits][kpad_w][cn_pad]
+ * into `ws`, then ctseg_conv_wgrad_reduce sums them in fixed order (deterministic) into torch layout.
+ * Replaces autograd's conv weight/bias backward for the same modules as above. */
+typedef struct ctseg_wgrad_desc {
+  const void* in;        /* gathered tensor [N][Xi][Yi][Zi][g_ld]  */
+  const void* dy;        /* [N][rows][d_ld], rows = Xr*Yr*Zr        */
+  float* ws;             /* slabs                                    */
+  int32_t dtype;
+  int32_t N, Xi, Yi, Zi, Xr, Yr, Zr;
+  int32_t Cg, Cn, g_ld, d_ld, sin;
+  int32_t ntaps;
+  int32_t taps[CTSEG_MAX_TAPS];
+  int32_t splits;        /* row ranges per sample                    */
+  int32_t kpad_w, cn_pad; /* slab dims: kpad_w = roundup(ntaps*Cg+1,128), cn_pad = roundup(Cn, tile cols) */
+} ctseg_wgrad_desc;
+
+int ctseg_wgrad_tile_cols(int32_t Cn);
+int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream);
+/* dw[(b*A + a)*T + t] = sum_s ws[s][t*Astride + a][col0 + b]  for a < A, b < nb;
+ * db[b] = sum_s ws[s][T*Astride][col0+b] (db may be NULL).  Astride = the pass's (padded) Cg. */
+int ctseg_conv_wgrad_reduce(const float* ws, int32_t nslabs, int32_t kpad_w, int32_t cn_pad, int32_t A, int32_t Astride,
+                            int32_t T, int32_t col0, int32_t nb, float* dw, float* db, void* stream);
+
+/* dst[i] = (dtype) src[idx[i]], i < n.  With a host-built index this turns the flat fp32 parameter buffer
+ * (torch Conv/ConvTranspose weight layouts) into every K-contiguous packed operand of the passes above in
+ * ONE launch per optimizer step; pad entries point at a zero element of src. */
+int ctseg_gather_cast(const float* src, const int32_t* idx, void* dst, int32_t dtype, int64_t n, void* stream);
+
+/* InstanceNorm3d(affine=False, eps) + PReLU(1 scalar), as MONAI's Convolution block applies them
+ * (SURVEY.md §3.2).  Statistics come from the conv pass's partials. */
+/* partials [N][P][2][ld] fp32 -> mean_rstd [N][C][2] fp32 (biased variance, fp64 combine, fixed order) */
+int ctseg_instnorm_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t col0, int32_t C, double count,
+                            double eps, double* scratch /* [N][64][2][ld] */, float* mean_rstd, void* stream);
+/* out = prelu((y-mean)*rstd, alpha) [+ res] ;  S = voxels per sample; mean_rstd NULL => identity norm/act skipped */
+int ctseg_instnorm_prelu_fwd(int32_t dtype, const void* y, int32_t y_ld, const float* mean_rstd, const float* alpha,
+                             const void* res, int32_t res_ld, void* out, int32_t out_ld, int32_t N, int64_t S, int32_t C,
+                             void* stream);
+/* backward, pass 1: partials [N][P][3][ld]: (sum dxhat, sum dxhat*xhat, sum g*xhat*[xhat<=0]) */
+int ctseg_instnorm_prelu_bwd_reduce(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
+                                    const float* mean_rstd, const float* alpha, float* partials, int32_t P, int32_t ld,
+                                    int32_t N, int64_t S, int32_t C, void* stream);
+/* partials -> sums [N][C][2] (already divided by S) and dalpha (scalar, overwritten) */
+int ctseg_instnorm_prelu_bwd_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t C, double S,
+                                      float* sums, float* dalpha, void* stream);
+/* backward, pass 2: dy = rstd*(dxhat - s1 - xhat*s2); optionally also copies g to g_copy (fused residual hand-off) */
+int ctseg_instnorm_prelu_bwd_apply(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
+                                   const float* mean_rstd, const float* alpha, const float* sums, void* dy, int32_t dy_ld,
+                                   void* g_copy, int32_t g_copy_ld, int32_t N, int64_t S, int32_t C, void* stream);
+
+/* out[c] = sum over rows of x[row][c] (bias gradient of nn.ConvTranspose3d); partials [P][roundup(C,chunk)] fp32 scratch */
+int ctseg_colsum(int32_t dtype, const void* x, int32_t ld, int64_t rows, int32_t C, float* partials, int32_t P, float* out,
+                 void* stream);
+
+/* _squash_masks_3D (capstone/volumetric/utils.py:4-7): masks u8 [B][K][S] -> labels u8 [B][S]
+ * (+ optional int64 copy) and per-sample class histogram hist[B][K+1] (int64, must be zeroed by the caller). */
+int ctseg_squash_masks(const uint8_t* masks, int32_t B, int32_t K, int64_t S, uint8_t* labels, int64_t* labels_i64,
+                       int64_t* hist, void* stream);
+
+/* Fused loss / metric pass over channels-last fp32 logits [B][S][ld], C classes (C <= 16).
+ * Replaces F.cross_entropy (capstone/models/losses.py:53,68), softmax->argmax (capstone/training/utils.py:19-20),
+ * the one-hot + compute_meandice counts (capstone/models/temp.py:173-214) and the soft-Dice / focal sums of
+ * monai DiceLoss / FocalLoss.  do_stats: per-workgroup partials part[B][P][2+3C] doubles
+ *   (sum w*nll, sum w, then per class sum p, sum p*y, sum focal) and integer counts cnt[B][3][C]
+ *   (|pred==c & true==c|, |pred==c|, |true==c|; int64, zeroed by the caller).
+ * do_grad: dlogits = coef-weighted gradient, coef[B][1+3C] fp32 = (ce_scale, a[C], b[C], f[C]):
+ *   ce_scale*w[t]*(p-onehot) + softmax-jacobian of (a_c*y_c + b_c) + focal term f_t.  dlogits dtype = gdtype. */
+int ctseg_seg_loss(const float* logits, int32_t ld, const uint8_t* labels, int32_t B, int64_t S, int32_t C,
+                   const float* class_weight, int32_t do_stats, double* part, int32_t P, int64_t* cnt, int32_t do_grad,
+                   const float* coef, void* dlogits, int32_t g_ld, int32_t gdtype, uint8_t* pred_out, void* stream);
+/* cnt[B][3][C] += (|pred==c & true==c|, |pred==c|, |true==c|) from two u8 label maps [B][S]
+ * (DiceMetricWrapper on squashed predictions, capstone/models/metrics.py:15-31); cnt zeroed by the caller. */
+int ctseg_dice_counts(const uint8_t* pred, const uint8_t* truth, int32_t B, int64_t S, int32_t C, int64_t* cnt, void* stream);
+/* part [B][P][R] doubles -> out [B][R] doubles, fixed order */
+int ctseg_reduce_partials_f64(const double* part, int32_t B, int32_t P, int32_t R, double* out, void* stream);
+
+/* torch.optim.Adam step (capstone/volumetric/base_trainer.py:113-114) on flat fp32 buffers. */
+int ctseg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int32_t step, float grad_scale, void* stream);
+
+/* Layout / dtype plumbing. */
+int ctseg_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, void* stream);
+/* fp32 [N][C][S] (torch NC*) -> dtype [N][S][ld] channels-last (pad channels zeroed) and back (fp32 out) */
+int ctseg_nc_to_cl(const float* src, void* dst, int32_t dtype, int32_t N, int32_t C, int64_t S, int32_t ld, void* stream);
+int ctseg_cl_to_nc(const void* src, int32_t dtype, float* dst, int32_t N, int32_t C, int64_t S, int32_t ld, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTSEG_HIP_H */

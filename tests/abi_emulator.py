@@ -1,0 +1,287 @@
+"""CPU emulator of the C ABI in include/ctseg_hip.h — TEST INFRASTRUCTURE.
+
+Interprets the programs recorded by capstone_amd.plan.Plan (and direct engine calls) on host memory
+with numpy, so that the host-side logic of the product (tap tables, packed-weight indices, channel
+strides and slices, the forward/backward graph, gradient placement) can be checked against the
+oracle WITHOUT a GPU.  fp32 storage only.  It is also the per-kernel specification the GPU tests
+compare the HIP kernels with.  Never imported by the product.
+"""
+import ctypes
+
+import numpy as np
+
+F32 = 0
+
+
+def mem(ptr, count, dtype=np.float32):
+    if not ptr or count <= 0:
+        return None
+    nbytes = int(count) * np.dtype(dtype).itemsize
+    return np.frombuffer((ctypes.c_char * nbytes).from_address(ptr), dtype=dtype)
+
+
+def cl_view(ptr, N, X, Y, Z, C, ld, dtype=np.float32):
+    """channels-last strided view (N,X,Y,Z,C) of memory starting at ptr with voxel stride ld"""
+    nvox = N * X * Y * Z
+    flat = mem(ptr, (nvox - 1) * ld + C, dtype)
+    it = flat.itemsize
+    return np.lib.stride_tricks.as_strided(flat, (N, X, Y, Z, C), (X * Y * Z * ld * it, Y * Z * ld * it, Z * ld * it, ld * it, it))
+
+
+def _i8(v):
+    v &= 255
+    return v - 256 if v > 127 else v
+
+
+def _gather(inp, rowgrid, sin, off):
+    """inp (N,Xi,Yi,Zi,C) -> (N,Xr,Yr,Zr,C) with zero fill outside"""
+    N, Xi, Yi, Zi, C = inp.shape
+    idx, ok = [], []
+    for r, s, d in zip(rowgrid, (Xi, Yi, Zi), off):
+        i = np.arange(r) * sin + d
+        ok.append((i >= 0) & (i < s))
+        idx.append(np.clip(i, 0, s - 1))
+    g = inp[:, idx[0]][:, :, idx[1]][:, :, :, idx[2]]
+    m = ok[0][:, None, None] & ok[1][None, :, None] & ok[2][None, None, :]
+    return g * m[None, :, :, :, None]
+
+
+class Emulator:
+    def __init__(self):
+        self.conv_tile_rows = lambda cn: 256 if cn <= 32 else 128
+
+    def run(self, prog):
+        for name, _, args in prog:
+            getattr(self, name[len("ctseg_"):])(*args)
+
+    # ---------------------------------------------------------------------------------------------
+    def conv_igemm(self, d):
+        assert d.dtype == F32
+        N, Cg, Cn, cs = d.N, d.Cg, d.Cn, d.Cn_store
+        inp = cl_view(d.in_, N, d.Xi, d.Yi, d.Zi, Cg, d.g_ld)
+        out = cl_view(d.out, N, d.Xo, d.Yo, d.Zo, cs, d.o_ld)
+        add = cl_view(d.add, N, d.Xo, d.Yo, d.Zo, cs, d.add_ld) if d.add else None
+        bias = mem(d.bias, Cn) if d.bias else np.zeros(Cn, np.float32)
+        rg = (d.Xr, d.Yr, d.Zr)
+        stats = None
+        if d.stats:
+            stats = mem(d.stats, N * d.stats_tiles * 2 * d.stats_ld).reshape(N, d.stats_tiles, 2, d.stats_ld)
+            stats[:] = 0
+        for ci in range(d.nclass):
+            k = d.cls[ci]
+            W = mem(d.w + 4 * k.w_off, Cn * k.kpad).reshape(Cn, k.kpad)
+            acc = np.zeros((N,) + rg + (Cn,), np.float32)
+            for j in range(k.ntaps):
+                tp = k.taps[j]
+                off = (_i8(tp), _i8(tp >> 8), _i8(tp >> 16))
+                acc += _gather(inp, rg, d.sin, off) @ W[:, j * Cg:(j + 1) * Cg].T
+            val = acc + bias
+            if stats is not None:
+                stats[:, d.stats_tile0, 0, :Cn] += val.sum(axis=(1, 2, 3))
+                stats[:, d.stats_tile0, 1, :Cn] += (val * val).sum(axis=(1, 2, 3))
+            full = np.zeros((N,) + rg + (cs,), np.float32)
+            full[..., :Cn] = val
+            sl = (slice(None), slice(k.ox, None, d.sout), slice(k.oy, None, d.sout), slice(k.oz, None, d.sout))
+            if d.sout == 1:
+                sl = (slice(None), slice(0, d.Xr), slice(0, d.Yr), slice(0, d.Zr))
+            else:
+                sl = (slice(None), slice(k.ox, k.ox + 2 * d.Xr, 2), slice(k.oy, k.oy + 2 * d.Yr, 2), slice(k.oz, k.oz + 2 * d.Zr, 2))
+            if add is not None:
+                full = full + add[sl]
+            out[sl] = full
+
+    def conv_wgrad(self, d):
+        assert d.dtype == F32
+        N, Cg, Cn = d.N, d.Cg, d.Cn
+        inp = cl_view(d.in_, N, d.Xi, d.Yi, d.Zi, Cg, d.g_ld)
+        dy = cl_view(d.dy, N, d.Xr, d.Yr, d.Zr, Cn, d.d_ld)
+        ws = mem(d.ws, N * d.splits * d.kpad_w * d.cn_pad).reshape(N * d.splits, d.kpad_w, d.cn_pad)
+        ws[:] = 0
+        dyf = dy.reshape(-1, Cn)
+        for j in range(d.ntaps):
+            tp = d.taps[j]
+            g = _gather(inp, (d.Xr, d.Yr, d.Zr), d.sin, (_i8(tp), _i8(tp >> 8), _i8(tp >> 16))).reshape(-1, Cg)
+            ws[0, j * Cg:(j + 1) * Cg, :Cn] = g.T @ dyf
+        ws[0, d.ntaps * Cg, :Cn] = dyf.sum(0)
+
+    def conv_wgrad_reduce(self, ws, nslabs, kpad_w, cn_pad, A, AS, T, col0, nb, dw, db):
+        w = mem(ws, nslabs * kpad_w * cn_pad).reshape(nslabs, kpad_w, cn_pad).sum(0)
+        r = w[:T * AS, col0:col0 + nb].reshape(T, AS, nb)[:, :A, :]           # [t][a][b]
+        mem(dw, nb * A * T)[:] = np.transpose(r, (2, 1, 0)).reshape(-1)      # [b][a][t]
+        if db:
+            mem(db, nb)[:] = w[T * AS, col0:col0 + nb]
+
+    def gather_cast(self, src, idx, dst, dtype, n):
+        assert dtype == F32
+        i = mem(idx, n, np.int32)
+        mem(dst, n)[:] = mem(src, int(i.max()) + 1)[i]
+
+    # ---------------------------------------------------------------------------------------------
+    def instnorm_finalize(self, partials, N, P, ld, col0, C, count, eps, scratch, mean_rstd):
+        p = mem(partials, N * P * 2 * ld).reshape(N, P, 2, ld).astype(np.float64).sum(1)
+        mean = p[:, 0, col0:col0 + C] / count
+        var = np.maximum(p[:, 1, col0:col0 + C] / count - mean * mean, 0)
+        mr = mem(mean_rstd, N * C * 2).reshape(N, C, 2)
+        mr[:, :, 0] = mean
+        mr[:, :, 1] = 1.0 / np.sqrt(var + eps)
+
+    @staticmethod
+    def _rows(ptr, N, S, C, ld):
+        return cl_view(ptr, N, S, 1, 1, C, ld).reshape(N, S, C) if ptr else None
+
+    def instnorm_prelu_fwd(self, dtype, y, y_ld, mean_rstd, alpha, res, res_ld, out, out_ld, N, S, C):
+        assert dtype == F32
+        Cp = (C + 3) // 4 * 4
+        yv = self._rows(y, N, S, C, y_ld).copy()
+        if mean_rstd:
+            mr = mem(mean_rstd, N * C * 2).reshape(N, 1, C, 2)
+            a = mem(alpha, 1)[0]
+            yv = (yv - mr[..., 0]) * mr[..., 1]
+            yv = np.where(yv > 0, yv, a * yv)
+        if res:
+            yv = yv + self._rows(res, N, S, C, res_ld)
+        o = self._rows(out, N, S, Cp, out_ld)
+        o[..., :C] = yv
+        o[..., C:] = 0
+
+    def _xhat(self, y, y_ld, mean_rstd, N, S, C):
+        mr = mem(mean_rstd, N * C * 2).reshape(N, 1, C, 2)
+        return (self._rows(y, N, S, C, y_ld) - mr[..., 0]) * mr[..., 1], mr[..., 1]
+
+    def instnorm_prelu_bwd_reduce(self, dtype, g, g_ld, y, y_ld, mean_rstd, alpha, partials, P, ld, N, S, C):
+        xh, _ = self._xhat(y, y_ld, mean_rstd, N, S, C)
+        gv = self._rows(g, N, S, C, g_ld)
+        a = mem(alpha, 1)[0]
+        dxh = gv * np.where(xh > 0, 1.0, a).astype(np.float32)
+        p = mem(partials, N * P * 3 * ld).reshape(N, P, 3, ld)
+        p[:] = 0
+        p[:, 0, 0, :C] = dxh.sum(1)
+        p[:, 0, 1, :C] = (dxh * xh).sum(1)
+        p[:, 0, 2, :C] = np.where(xh > 0, 0, gv * xh).sum(1)
+
+    def instnorm_prelu_bwd_finalize(self, partials, N, P, ld, C, S, sums, dalpha):
+        p = mem(partials, N * P * 3 * ld).reshape(N, P, 3, ld).astype(np.float64).sum(1)
+        s = mem(sums, N * C * 2).reshape(N, C, 2)
+        s[:, :, 0] = p[:, 0, :C] / S
+        s[:, :, 1] = p[:, 1, :C] / S
+        mem(dalpha, 1)[0] = p[:, 2, :C].sum()
+
+    def instnorm_prelu_bwd_apply(self, dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C):
+        xh, rstd = self._xhat(y, y_ld, mean_rstd, N, S, C)
+        gv = self._rows(g, N, S, C, g_ld)
+        a = mem(alpha, 1)[0]
+        s = mem(sums, N * C * 2).reshape(N, 1, C, 2)
+        dxh = gv * np.where(xh > 0, 1.0, a).astype(np.float32)
+        Cp = (C + 3) // 4 * 4
+        o = self._rows(dy, N, S, Cp, dy_ld)
+        o[..., :C] = rstd * (dxh - s[..., 0] - xh * s[..., 1])
+        o[..., C:] = 0
+        if g_copy:
+            self._rows(g_copy, N, S, Cp, g_copy_ld)[:] = self._rows(g, N, S, Cp, g_ld)
+
+    def colsum(self, dtype, x, ld, rows, C, partials, P, out):
+        mem(out, C)[:] = cl_view(x, 1, rows, 1, 1, C, ld).reshape(rows, C).astype(np.float64).sum(0)
+
+    # ---------------------------------------------------------------------------------------------
+    def squash_masks(self, masks, B, K, S, labels, labels_i64, hist):
+        m = mem(masks, B * K * S, np.uint8).reshape(B, K, S).astype(np.int64)
+        lab = (m * np.arange(1, K + 1)[None, :, None]).max(1)
+        mem(labels, B * S, np.uint8)[:] = lab.reshape(-1).astype(np.uint8)
+        if labels_i64:
+            mem(labels_i64, B * S, np.int64)[:] = lab.reshape(-1)
+        if hist:
+            h = mem(hist, B * (K + 1), np.int64).reshape(B, K + 1)
+            for b in range(B):
+                h[b] += np.bincount(lab[b], minlength=K + 1)[:K + 1]
+
+    def seg_loss(self, logits, ld, labels, B, S, C, class_weight, do_stats, part, P, cnt, do_grad, coef, dlogits, g_ld, gdtype,
+                 pred_out):
+        x = cl_view(logits, B, S, 1, 1, C, ld).reshape(B, S, C)
+        t = mem(labels, B * S, np.uint8).reshape(B, S).astype(np.int64)
+        cw = mem(class_weight, C) if class_weight else np.ones(C, np.float32)
+        m = x.max(-1, keepdims=True)
+        e = np.exp(x - m)
+        ssum = e.sum(-1, keepdims=True, dtype=np.float32)
+        p = e / ssum
+        pred = p.argmax(-1)
+        lse = (m + np.log(ssum))[..., 0]
+        oh = np.eye(C, dtype=np.float32)[t]
+        xt, pt = (x * oh).sum(-1), (p * oh).sum(-1)
+        w = cw[t]
+        if pred_out:
+            mem(pred_out, B * S, np.uint8)[:] = pred.reshape(-1).astype(np.uint8)
+        if do_stats:
+            R = 2 + 3 * C
+            pr = mem(part, B * P * R, np.float64).reshape(B, P, R)
+            pr[:] = 0
+            pr[:, 0, 0] = (w * (lse - xt)).astype(np.float64).sum(1)
+            pr[:, 0, 1] = w.astype(np.float64).sum(1)
+            pr[:, 0, 2:2 + C] = p.astype(np.float64).sum(1)
+            pr[:, 0, 2 + C:2 + 2 * C] = (p * oh).astype(np.float64).sum(1)
+            fo = -(1 - pt) ** 2 * (xt - lse)
+            pr[:, 0, 2 + 2 * C:] = (fo[..., None] * oh).astype(np.float64).sum(1)
+            c = mem(cnt, B * 3 * C, np.int64).reshape(B, 3, C)
+            ph = np.eye(C, dtype=np.int64)[pred]
+            c[:, 0] += (ph * oh.astype(np.int64)).sum(1)
+            c[:, 1] += ph.sum(1)
+            c[:, 2] += oh.astype(np.int64).sum(1)
+        if do_grad:
+            assert gdtype == F32
+            cf = mem(coef, B * (1 + 3 * C)).reshape(B, 1 + 3 * C)
+            a, b, f = cf[:, None, 1:1 + C], cf[:, None, 1 + C:1 + 2 * C], cf[:, None, 1 + 2 * C:]
+            gk = b + a * oh
+            dot = (gk * p).sum(-1, keepdims=True)
+            ft = (f * oh).sum(-1)
+            om, logpt = 1 - pt, xt - lse
+            fterm = ft * (2 * om * pt * logpt - om * om)
+            d = cf[:, None, 0:1] * w[..., None] * (p - oh) + p * (gk - dot) + fterm[..., None] * (oh - p)
+            o = cl_view(dlogits, B, S, 1, 1, g_ld, g_ld).reshape(B, S, g_ld)
+            o[..., :C] = d
+            o[..., C:] = 0
+
+    def reduce_partials_f64(self, part, B, P, R, out):
+        mem(out, B * R, np.float64)[:] = mem(part, B * P * R, np.float64).reshape(B, P, R).sum(1).reshape(-1)
+
+    def dice_counts(self, pred, truth, B, S, C, cnt):
+        p = mem(pred, B * S, np.uint8).reshape(B, S)
+        t = mem(truth, B * S, np.uint8).reshape(B, S)
+        c = mem(cnt, B * 3 * C, np.int64).reshape(B, 3, C)
+        for b in range(B):
+            c[b, 1] += np.bincount(p[b], minlength=C)[:C]
+            c[b, 2] += np.bincount(t[b], minlength=C)[:C]
+            c[b, 0] += np.bincount(p[b][p[b] == t[b]], minlength=C)[:C]
+
+    def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, step, gscale):
+        P, G, M, V = (mem(q, n) for q in (p, g, m, v))
+        gr = G * np.float32(gscale)
+        M[:] = M + (gr - M) * np.float32(1 - b1)
+        V[:] = V * np.float32(b2) + np.float32(1 - b2) * gr * gr
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        P[:] = P - np.float32(lr / bc1) * (M / (np.sqrt(V) / np.float32(np.sqrt(bc2)) + np.float32(eps)))
+
+    def cast(self, src, sd, dst, dd, n):
+        assert sd == F32 and dd == F32
+        mem(dst, n)[:] = mem(src, n)
+
+    def nc_to_cl(self, src, dst, dtype, N, C, S, ld):
+        s = mem(src, N * C * S).reshape(N, C, S)
+        d = mem(dst, N * S * ld).reshape(N, S, ld)
+        d[:] = 0
+        d[..., :C] = np.transpose(s, (0, 2, 1))
+
+    def cl_to_nc(self, src, dtype, dst, N, C, S, ld):
+        s = mem(src, N * S * ld).reshape(N, S, ld)
+        mem(dst, N * C * S).reshape(N, C, S)[:] = np.transpose(s[..., :C], (0, 2, 1))
+
+
+def patch_native(nat, emu):
+    """route capstone_amd._native.call (direct engine calls) through the emulator; returns an undo callable"""
+    orig_call, orig_stream = nat.call, nat.stream_ptr
+    nat.call = lambda name, *args: getattr(emu, name[len("ctseg_"):])(*args)
+    nat.stream_ptr = lambda: None
+    orig_req = nat.require_gpu
+    nat.require_gpu = lambda t, what: None
+
+    def undo():
+        nat.call, nat.stream_ptr, nat.require_gpu = orig_call, orig_stream, orig_req
+    return undo
