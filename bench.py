@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — CT volumes/sec of the 3-D U-Net training step (BASELINE.json's metric) on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic batch already resident in HBM: squash masks -> UNet forward
+-> fused CE + Dice counts -> backward (dgrad + wgrad) -> [RCCL all-reduce of the flat gradient] -> Adam.
+Workload = BASELINE.json configs[2]: MONAI-shaped UNet(3,1,10,(32,64,128,256),(2,2,2,2),num_res_units=2),
+2 x 1 x 512 x 512 x 48 per GPU, bf16 storage / fp32 accumulate (weak scaling: per-GPU batch fixed).
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (encoder-bottleneck Conv3d,
+timed with HIP events around its launches inside the timed steps) and `cpu_baseline` (the oracle step on the
+host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "ct-image-segmentation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+FILTERS = [32, 64, 128, 256]
+SEED = 12342
+PEAK_BF16_TFLOPS = 2500.0          # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def synthetic_batch(B, H, W, D, device, seed):
+    """randn images; 9 non-overlapping axis-aligned ellipsoids (~1.3 % foreground); all annotated."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    images = torch.randn(B, 1, H, W, D, device=device, generator=g)
+    masks = torch.zeros(B, 9, H, W, D, dtype=torch.uint8, device=device)
+    xs = torch.arange(H, device=device).view(H, 1, 1).float()
+    ys = torch.arange(W, device=device).view(1, W, 1).float()
+    zs = torch.arange(D, device=device).view(1, 1, D).float()
+    rel = [0.007, 0.3296, 0.0046, 0.2619, 0.3035, 0.0068, 0.0065, 0.0374, 0.0426]   # sizes ~ 1/WEIGHT
+    vol = torch.tensor([1.0 / r for r in rel])
+    vol = vol / vol.sum() * 0.0134 * H * W * D
+    for c in range(9):
+        cx, cy, cz = H * (0.15 + 0.08 * c), W * (0.2 + 0.07 * ((c * 5) % 9)), D * 0.5
+        r = (float(vol[c]) * 3 / (4 * 3.14159)) ** (1 / 3)
+        rz = min(r, D * 0.4)
+        rxy = (float(vol[c]) * 3 / (4 * 3.14159 * rz)) ** 0.5
+        m = ((xs - cx) / rxy) ** 2 + ((ys - cy) / rxy) ** 2 + ((zs - cz) / rz) ** 2 <= 1.0
+        masks[:, c] = m.to(torch.uint8)
+    # make them non-overlapping: a later class never claims a voxel an earlier one has
+    taken = torch.zeros(B, H, W, D, dtype=torch.bool, device=device)
+    for c in range(9):
+        masks[:, c] &= (~taken).to(torch.uint8)
+        taken |= masks[:, c].bool()
+    return images, masks, torch.ones(B, 9, device=device)
+
+
+def find_op(plan, name_sub, cin, cout):
+    """index of the conv pass named like `name_sub` in the recorded forward program"""
+    import capstone_amd._native as nat
+    for i, (name, _, args) in enumerate(plan.fwd):
+        if name == "ctseg_conv_igemm":
+            d = args[0]
+            if d.Cg == cin and d.Cn == cout and d.nclass == 1 and d.cls[0].ntaps == 27 and d.sin == 1:
+                return i
+    return None
+
+
+def cpu_baseline(shape, threads):
+    """the oracle (torch CPU restatement of the reference step) on the host cores: kind = "port"."""
+    from oracle.trainer import OracleUNet3D
+    torch.set_num_threads(threads)
+    torch.manual_seed(SEED)
+    m = OracleUNet3D(filters=FILTERS, loss_fx=("CrossEntropy",))
+    opt = m.configure_optimizers()
+    B, H, W, D = shape
+    batch = synthetic_batch(B, H, W, D, "cpu", SEED)
+    t0 = time.time()
+    m.fit_step(batch, opt)
+    dt = time.time() - t0
+    return {"value": B / dt, "unit": "volumes/s", "cores": threads, "kind": "port",
+            "sample": f"1 training step (fwd+loss+Dice+bwd+Adam) of the oracle on {B}x1x{H}x{W}x{D} fp32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--shape", type=int, nargs=4, default=[2, 512, 512, 48], metavar=("B", "H", "W", "D"))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-shape", type=int, nargs=4, default=[1, 256, 256, 48])
+    args = ap.parse_args()
+
+    from capstone_amd import distributed as cdist
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+
+    rank, local, world = cdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    B, H, W, D = args.shape
+
+    torch.manual_seed(SEED)
+    model = BaseUNet3D(filters=list(FILTERS), loss_fx=["CrossEntropy"], precision=args.precision, batch_size=B).to(dev)
+    batch = synthetic_batch(B, H, W, D, dev, SEED + rank)
+    model.fit_step(batch)                     # builds the plan (untimed, counted as warmup 0)
+    if world > 1:
+        cdist.attach(model)
+    for _ in range(max(args.warmup - 1, 0)):
+        model.fit_step(batch)
+
+    eng = model.unet.engine()
+    plan = eng.last_plan
+    probe_i = find_op(plan, "bottleneck", 256, 256)
+    ev = []
+    if probe_i is not None:
+        orig_run = plan.run
+
+        def run_probed(prog, stream, lo=0, hi=None):
+            if prog is plan.fwd:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                orig_run(prog, stream, 0, probe_i)
+                a.record()
+                orig_run(prog, stream, probe_i, probe_i + 1)
+                b.record()
+                orig_run(prog, stream, probe_i + 1, None)
+                ev.append((a, b))
+            else:
+                orig_run(prog, stream, lo, hi)
+        plan.run = run_probed
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = model.fit_step(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_v = float(loss.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {"metric": "CT volumes/sec training (512x512x48, bs=2/GPU)", "value": world * B * args.steps / elapsed,
+               "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+               "config": {"workload": f"3D U-Net (MONAI UNet, channels 32-64-128-256, 2 res units) training step on "
+                                      f"{B}x1x{H}x{W}x{D} synthetic CT volumes per GPU (BASELINE.json configs[2]"
+                                      f"{'' if world == 1 else '/[3]'}), CrossEntropy + Dice metric + Adam",
+                          "global_batch": world * B, "parallelism": f"dp{world}", "loss_last_step": loss_v}}
+        if ev:
+            kms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            n_, x_, y_, z_ = B, H // 8, W // 8, D // 8
+            flop = 2.0 * n_ * x_ * y_ * z_ * 256 * 256 * 27
+            peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+            ach = flop / (kms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                               "traffic": None, "kernel": "conv_igemm_kernel<BF16,128,128> encoder-bottleneck Conv3d 256->256 k3",
+                               "launch_ms": kms, "flop_per_launch": flop}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(tuple(args.cpu_shape), os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

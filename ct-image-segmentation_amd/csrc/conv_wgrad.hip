@@ -32,7 +32,7 @@ template <typename T, int BNW> struct WgradCfg {
   static constexpr int STAGE = 32 * (PA + PD);
 };
 
-template <typename T, int BNW, int WK, int WC>
+template <typename T, int BNW, int WK, int WC, bool SMALLC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
   constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
   using CF = WgradCfg<T, BNW>;
@@ -46,7 +46,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
   static_assert(WK * WC == 4 && KT >= 1 && CT >= 1, "4 waves");
 
   __shared__ __attribute__((aligned(16))) char smem[2 * CF::STAGE];
+  __shared__ int sTap[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 32) sTap[tid] = tid < P.ntaps ? P.taps[tid] : 0;
+  __syncthreads();
   const int wk = wave / WC, wc = wave % WC;
   const int r16 = lane & 15, q4 = lane >> 4;
   const int kblock = blockIdx.x, col0 = blockIdx.y * BNW;
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
   const bool kvalid = kpos < ktot, kones = kpos == ktot;
   int dx = 0, dy_ = 0, dz = 0;
   if (kvalid) {
-    const int tp = P.taps[slot];
+    const int tp = sTap[slot & 31];
     dx = (int)(int8_t)(tp & 0xff); dy_ = (int)(int8_t)((tp >> 8) & 0xff); dz = (int)(int8_t)((tp >> 16) & 0xff);
   }
   int cx[AJ], cy[AJ], cz[AJ];
@@ -86,7 +89,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
     for (int j = 0; j < AJ; ++j) {
       const int m = mb + arow0 + j * ARS;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (m < mend) {
+      if constexpr (SMALLC) {
+        // gathered channel count is not a multiple of the 16-byte chunk (the Cin = 1 stem): element-wise gather
+        if (m < mend) {
+          uint32_t el[EPC];
+#pragma unroll
+          for (int t = 0; t < EPC; ++t) {
+            const int kp = kpos + t;
+            uint32_t val = 0u;
+            if (kp < ktot) {
+              const int sl = kp / P.Cg, c = kp - sl * P.Cg;
+              const int tp = sTap[sl & 31];
+              const int xi = cx[j] * P.sin + (int)(int8_t)(tp & 0xff), yi = cy[j] * P.sin + (int)(int8_t)((tp >> 8) & 0xff),
+                        zi = cz[j] * P.sin + (int)(int8_t)((tp >> 16) & 0xff);
+              if ((unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi) {
+                const int64_t vox = ((nbase + xi) * P.Yi + yi) * P.Zi + zi;
+                const char* p = P.in + (vox * P.g_ld + c) * SZ;
+                if constexpr (SZ == 4) val = *reinterpret_cast<const uint32_t*>(p);
+                else val = *reinterpret_cast<const unsigned short*>(p);
+              }
+            } else if (kp == ktot) {
+              val = (SZ == 4) ? 0x3f800000u : 0x3f80u;
+            }
+            el[t] = val;
+          }
+          if constexpr (SZ == 4) { v[0] = el[0]; v[1] = el[1]; v[2] = el[2]; v[3] = el[3]; }
+          else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = el[2 * t] | (el[2 * t + 1] << 16);
+          }
+        }
+      } else if (m < mend) {
         if (kvalid) {
           const int xi = cx[j] * P.sin + dx, yi = cy[j] * P.sin + dy_, zi = cz[j] * P.sin + dz;
           if ((unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi) {
@@ -223,13 +256,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int nslabs, in
   }
 }
 
-template <typename T> static void launch_wgrad(const WgradKArgs& a, hipStream_t st) {
+template <typename T, bool SMALLC> static void launch_wgrad(const WgradKArgs& a, hipStream_t st) {
   const int bnw = ctseg_wgrad_tile_cols(a.Cn);
   dim3 grid((unsigned)(a.kpad_w / 128), (unsigned)(a.cn_pad / bnw), (unsigned)(a.N * a.splits));
-  if (bnw == 16) hipLaunchKernelGGL((conv_wgrad_kernel<T, 16, 4, 1>), grid, dim3(256), 0, st, a);
-  else if (bnw == 32) hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 2, 2>), grid, dim3(256), 0, st, a);
-  else if (bnw == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 2, 2>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 2, 2>), grid, dim3(256), 0, st, a);
+  if (bnw == 16) hipLaunchKernelGGL((conv_wgrad_kernel<T, 16, 4, 1, SMALLC>), grid, dim3(256), 0, st, a);
+  else if (bnw == 32) hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 2, 2, SMALLC>), grid, dim3(256), 0, st, a);
+  else if (bnw == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 2, 2, SMALLC>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 2, 2, SMALLC>), grid, dim3(256), 0, st, a);
 }
 
 }  // namespace ctseg
@@ -242,8 +275,8 @@ extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
   CTSEG_REQUIRE(d != nullptr && d->in && d->dy && d->ws, "conv_wgrad: null pointer");
   CTSEG_REQUIRE(d->dtype == CTSEG_F32 || d->dtype == CTSEG_BF16, "conv_wgrad: bad dtype");
   const int SZ = d->dtype == CTSEG_F32 ? 4 : 2, EPC = 16 / SZ;
-  CTSEG_REQUIRE(d->Cg % EPC == 0 && d->g_ld % EPC == 0 && d->d_ld % EPC == 0, "conv_wgrad: channels must be 16-byte chunked");
-  CTSEG_REQUIRE(((uintptr_t)d->in % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "conv_wgrad: unaligned operand");
+  CTSEG_REQUIRE(d->d_ld % EPC == 0 && ((uintptr_t)d->dy % 16) == 0, "conv_wgrad: dy must be 16-byte chunked");
+  const bool smallc = (d->Cg % EPC) != 0 || (d->g_ld % EPC) != 0 || ((uintptr_t)d->in % 16) != 0;
   CTSEG_REQUIRE(d->ntaps >= 1 && d->ntaps <= CTSEG_MAX_TAPS && d->splits >= 1, "conv_wgrad: ntaps/splits");
   const int bnw = ctseg_wgrad_tile_cols(d->Cn);
   const int ktot = d->ntaps * d->Cg;
@@ -267,8 +300,8 @@ extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
   a.sy = step % d->Yr; a.sx = step / d->Yr;
   for (int i = 0; i < CTSEG_MAX_TAPS; ++i) a.taps[i] = i < d->ntaps ? d->taps[i] : 0;
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == CTSEG_F32) launch_wgrad<float>(a, st);
-  else launch_wgrad<BF16>(a, st);
+  if (d->dtype == CTSEG_F32) { if (smallc) launch_wgrad<float, true>(a, st); else launch_wgrad<float, false>(a, st); }
+  else { if (smallc) launch_wgrad<BF16, true>(a, st); else launch_wgrad<BF16, false>(a, st); }
   CTSEG_LAUNCH_CHECK("conv_wgrad");
   return 0;
 }
