@@ -331,7 +331,7 @@ class GemmLayer:
         bnw = lib.ctseg_wgrad_tile_cols(cn)
         kpad_w, cn_pad = rup(self.T * cg + 1, 128), rup(cn, bnw)
         nwg = (kpad_w // 128) * (cn_pad // bnw) * N
-        splits = max(1, min(math.ceil(1024 / nwg), math.ceil(rows / 256), 64))
+        splits = max(1, min(math.ceil(2048 / nwg), math.ceil(rows / 512), 1024))
         ws = torch.zeros(N * splits * kpad_w * cn_pad, dtype=torch.float32, device=plan.device)
         d = nat.WgradDesc()
         d.in_, d.dy, d.ws, d.dtype = gathered.ptr(), dyy.ptr(), ws.data_ptr(), plan.dt

@@ -47,7 +47,7 @@ class _NormAct:
         """g = dL/d(activation). Returns dL/dy (raw conv output); alpha's gradient goes to the flat buffer."""
         plan, y = self.plan, self.y
         N, S, C = y.dims[0], y.S, y.C
-        P = max(1, min(256, math.ceil(S / 2048)))
+        P = max(1, min(1024, math.ceil(S / 512)))
         ld = rup(C, 4)
         part = torch.zeros((N, P, 3, ld), dtype=torch.float32, device=plan.device)
         sums = torch.zeros((N, C, 2), dtype=torch.float32, device=plan.device)

@@ -136,28 +136,47 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_reduce_kernel(const ch
   }
 }
 
-__global__ void instnorm_prelu_bwd_finalize_kernel(const float* __restrict__ partials, int N, int P, int ld, int C, double S,
-                                                   float* __restrict__ sums, float* __restrict__ dalpha) {
-  __shared__ double s_da[256];
+__global__ __launch_bounds__(1024) void instnorm_prelu_bwd_finalize_kernel(const float* __restrict__ partials, int N, int P, int ld,
+                                                                            int C, double S, float* __restrict__ sums,
+                                                                            float* __restrict__ dalpha) {
+  // one block; thread = (sub, n*C + c): `subs` strided sub-sums per (n,c), combined in fixed order (deterministic)
+  __shared__ double s_acc[1024 * 3];
+  __shared__ double s_da[1024];
+  const int NC = N * C;
+  const int subs = NC >= 1024 ? 1 : 1024 / NC;
   double da = 0.0;
-  for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
-    const int n = i / C, c = i - n * C;
+  for (int base = 0; base < NC; base += 1024 / subs * 1) {
+    const int lanes = 1024 / subs;                      // (n,c) pairs handled per sweep
+    const int i = base + (int)threadIdx.x % lanes, sub = (int)threadIdx.x / lanes;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int p = 0; p < P; ++p) {
-      const float* q = partials + ((int64_t)n * P + p) * 3 * ld + c;
-      s1 += (double)q[0];
-      s2 += (double)q[ld];
-      s3 += (double)q[2 * ld];
+    if (i < NC && sub < subs) {
+      const int n = i / C, c = i - n * C;
+      for (int p = sub; p < P; p += subs) {
+        const float* q = partials + ((int64_t)n * P + p) * 3 * ld + c;
+        s1 += (double)q[0];
+        s2 += (double)q[ld];
+        s3 += (double)q[2 * ld];
+      }
     }
-    sums[(int64_t)i * 2] = (float)(s1 / S);
-    sums[(int64_t)i * 2 + 1] = (float)(s2 / S);
-    da += s3;
+    s_acc[threadIdx.x * 3] = s1; s_acc[threadIdx.x * 3 + 1] = s2; s_acc[threadIdx.x * 3 + 2] = s3;
+    __syncthreads();
+    if (sub == 0 && i < NC) {
+      double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+      for (int k = 0; k < subs; ++k) {
+        const int t = k * lanes + (int)threadIdx.x;
+        t1 += s_acc[t * 3]; t2 += s_acc[t * 3 + 1]; t3 += s_acc[t * 3 + 2];
+      }
+      sums[(int64_t)i * 2] = (float)(t1 / S);
+      sums[(int64_t)i * 2 + 1] = (float)(t2 / S);
+      da += t3;
+    }
+    __syncthreads();
   }
   s_da[threadIdx.x] = da;
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
-    for (int i = 0; i < (int)blockDim.x; ++i) t += s_da[i];
+    for (int i = 0; i < 1024; ++i) t += s_da[i];
     dalpha[0] = (float)t;
   }
 }
@@ -312,7 +331,7 @@ extern "C" int ctseg_instnorm_prelu_bwd_reduce(int32_t dtype, const void* g, int
 extern "C" int ctseg_instnorm_prelu_bwd_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t C, double S,
                                                  float* sums, float* dalpha, void* stream) {
   CTSEG_REQUIRE(partials && sums && dalpha && N > 0 && P > 0 && C > 0, "instnorm_prelu_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(instnorm_prelu_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, N, P, ld, C, S,
+  hipLaunchKernelGGL(instnorm_prelu_bwd_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, N, P, ld, C, S,
                      sums, dalpha);
   CTSEG_LAUNCH_CHECK("instnorm_prelu_bwd_finalize");
   return 0;
