@@ -69,6 +69,7 @@ _SIGS = {
     "ctseg_last_error": (C.c_char_p, []),
     "ctseg_conv_tile_rows": (C.c_int, [_i32]),
     "ctseg_conv_tile_cols": (C.c_int, [_i32]),
+    "ctseg_conv_num_tiles": (C.c_int, [C.POINTER(ConvDesc)]),
     "ctseg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "ctseg_wgrad_tile_cols": (C.c_int, [_i32]),
     "ctseg_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),

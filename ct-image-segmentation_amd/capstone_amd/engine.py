@@ -285,12 +285,13 @@ class GemmLayer:
         else:
             rowgrid, sin, sout = od[1:], (1 if self.transposed else self.s), 1
         stats = None
-        if want_stats:
-            rows = rowgrid[0] * rowgrid[1] * rowgrid[2]
-            tiles = math.ceil(rows / nat.lib().ctseg_conv_tile_rows(self.Cn)) * len(self.fwd_classes)
-            stats = NormStats(plan, od[0], tiles, self.Cn, od[1] * od[2] * od[3])
         bias_ptr = plan.packer.bias_ptr(self.bias_off)
-        d = self._desc(self.fwd_pack, self.fwd_classes, x, out, rowgrid, sin, sout, self.Cn, self.cg, bias_ptr, add, stats, out_f32)
+        d = self._desc(self.fwd_pack, self.fwd_classes, x, out, rowgrid, sin, sout, self.Cn, self.cg, bias_ptr, add, None, out_f32)
+        if want_stats:
+            tiles = nat.lib().ctseg_conv_num_tiles(d)
+            assert tiles > 0
+            stats = NormStats(plan, od[0], tiles, self.Cn, od[1] * od[2] * od[3])
+            d.stats, d.stats_ld, d.stats_tiles, d.stats_tile0 = stats.partials.data_ptr(), stats.ld, stats.tiles, 0
         plan.emit("ctseg_conv_igemm", d, keep=(x, out, add, stats))
         return out, stats
 

@@ -1,0 +1,138 @@
+// Shared pieces of the implicit-GEMM convolution kernels (generic gather kernel + LDS-halo kernel).
+#pragma once
+#include "ctseg_dev.h"
+
+namespace ctseg {
+
+struct ConvKArgs {
+  const char* in;
+  const char* w;
+  const float* bias;
+  char* out;
+  const char* add;
+  float* stats;
+  int N, Xi, Yi, Zi, Xr, Yr, Zr, Xo, Yo, Zo;
+  int Cg, Cn, Cn_store, g_ld, o_ld, add_ld;
+  int sin, sout;
+  int rows, tiles;
+  int out_f32, add_f32;
+  int stats_ld, stats_tiles, stats_tile0;
+  ctseg_conv_class cls[CTSEG_MAX_CLASSES];
+};
+
+template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag);
+template <> __device__ __forceinline__ void mma16<BF16>(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, xfrag), acc,
+                                                0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wfrag[s]), __uint_as_float(xfrag[s]), acc, 0, 0, 0);
+}
+
+// Epilogue shared by both kernels.  Lane holds, for MFMA tile (j,i): voxel row = wm*WTM + i*16 + r16 of the
+// workgroup tile, channels wn*WTN + j*16 + 4*q4 + {0..3}.  sRow[2r] = xr | yr<<16, sRow[2r+1] = zr (or < 0: no voxel).
+// + bias, per-(tile, channel) sum / sumsq partials, transpose through LDS (`smem`, BM*(BN*OSZ+16) bytes),
+// optional addend, 16-byte coalesced channels-last stores.  Ends with all LDS reads done but NO trailing barrier.
+template <typename T, int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_conv_class& K, char* smem, float* sStats,
+                                              const int* sRow, f32x4 (&acc)[BN / WGN / 16][BM / WGM / 16], int n, int tile,
+                                              int cls_index, int col0) {
+  constexpr int SZ = TT<T>::SZ;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN, MT = WTM / 16, NT = WTN / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  // lane holds, for MFMA tile (j,i): voxel row = wm*WTM + i*16 + r16, channels wn*WTN + j*16 + 4*q4 + {0..3}
+  const bool of32 = P.out_f32 != 0;
+  const int OSZ = of32 ? 4 : SZ;
+  const int crow = BN * OSZ + 16;
+  float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ch = col0 + wn * WTN + j * 16 + 4 * q4;
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bv[e] = (P.bias != nullptr && ch + e < P.Cn) ? P.bias[ch + e] : 0.f;
+      ssum[j][e] = 0.f;
+      ssq[j][e] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int r = wm * WTM + i * 16 + r16;
+      const bool rv = sRow[2 * r + 1] >= 0;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = acc[j][i][e] + bv[e];
+        if (rv) { ssum[j][e] += v[e]; ssq[j][e] += v[e] * v[e]; }
+      }
+      char* cp = smem + r * crow + (wn * WTN + j * 16 + 4 * q4) * OSZ;
+      if (of32 || SZ == 4) {
+        *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+        *reinterpret_cast<u32x2*>(cp) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      }
+    }
+  }
+  if (P.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = ssum[j][e], b = ssq[j][e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (r16 == 0) {
+          const int c = wn * WTN + j * 16 + 4 * q4 + e;
+          sStats[(wm * 2 + 0) * BN + c] = a;
+          sStats[(wm * 2 + 1) * BN + c] = b;
+        }
+      }
+  }
+  __syncthreads();
+  if (P.stats != nullptr && tid < 2 * BN) {
+    const int which = tid / BN, c = tid % BN;
+    float a = 0.f;
+#pragma unroll
+    for (int m = 0; m < WGM; ++m) a += sStats[(m * 2 + which) * BN + c];
+    const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + (int64_t)cls_index * P.tiles + tile;
+    P.stats[(slot_t * 2 + which) * P.stats_ld + col0 + c] = a;
+  }
+  {
+    const int EPO = 16 / OSZ;               // output elements per 16-byte chunk
+    const int cpr = BN / EPO;                // chunks per tile row
+    const bool af32 = P.add_f32 != 0;
+    const int ASZ = af32 ? 4 : SZ;
+    for (int idx = tid; idx < BM * cpr; idx += 256) {
+      const int r = idx / cpr, cc = idx - r * cpr;
+      const int ch = col0 + cc * EPO;
+      const int z = sRow[2 * r + 1];
+      if (z < 0 || ch >= P.Cn_store) continue;
+      const int xy = sRow[2 * r];
+      const int64_t vox = (((int64_t)n * P.Xo + (xy & 0xffff) * P.sout + K.ox) * P.Yo + (xy >> 16) * P.sout + K.oy) * P.Zo +
+                          z * P.sout + K.oz;
+      const char* cp = smem + r * crow + cc * 16;
+      char* op = P.out + (vox * P.o_ld + ch) * OSZ;
+      if (P.add == nullptr) {
+        *reinterpret_cast<u32x4*>(op) = *reinterpret_cast<const u32x4*>(cp);
+      } else {
+        float v[8], a[8];
+        load_n_as_float(cp, of32 || SZ == 4, EPO, v);
+        load_n_as_float(P.add + (vox * P.add_ld + ch) * ASZ, af32 || SZ == 4, EPO, a);
+        for (int e = 0; e < EPO; ++e) v[e] += a[e];
+        if (of32 || SZ == 4) store_chunk<float>(op, v);
+        else store_chunk<BF16>(op, v);
+      }
+    }
+  }
+}
+
+// LDS-halo kernel (conv_halo.hip): 3x3x3 stride-1 passes with few channels, input tile staged once for all 27 taps
+bool conv_halo_eligible(const ConvKArgs& a, int dtype, int nclass);
+int conv_halo_tiles(const ConvKArgs& a);
+void launch_conv_halo(ConvKArgs& a, int dtype, hipStream_t st);
+
+}  // namespace ctseg

@@ -12,36 +12,9 @@
 // so each lane ends up with 4 consecutive output channels of one voxel -> channels-last epilogue.
 // Epilogue: + bias, per-(tile, channel) sum / sum-of-squares partials for InstanceNorm, transpose
 // through LDS, optional addend (residual / gradient accumulation), 16-byte coalesced stores.
-#include "ctseg_dev.h"
+#include "conv_common.h"
 
 namespace ctseg {
-
-struct ConvKArgs {
-  const char* in;
-  const char* w;
-  const float* bias;
-  char* out;
-  const char* add;
-  float* stats;
-  int N, Xi, Yi, Zi, Xr, Yr, Zr, Xo, Yo, Zo;
-  int Cg, Cn, Cn_store, g_ld, o_ld, add_ld;
-  int sin, sout;
-  int rows, tiles;
-  int out_f32, add_f32;
-  int stats_ld, stats_tiles, stats_tile0;
-  ctseg_conv_class cls[CTSEG_MAX_CLASSES];
-};
-
-template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag);
-template <> __device__ __forceinline__ void mma16<BF16>(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, xfrag), acc,
-                                                0, 0, 0);
-}
-template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag) {
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wfrag[s]), __uint_as_float(xfrag[s]), acc, 0, 0, 0);
-}
 
 template <int BM, int BN> struct ConvSmem {
   static constexpr int BKB = 128;
@@ -214,91 +187,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs P) {
     __syncthreads();
   }
 
-  // ---- epilogue ---------------------------------------------------------------------------------
-  // lane holds, for MFMA tile (j,i): voxel row = wm*WTM + i*16 + r16, channels wn*WTN + j*16 + 4*q4 + {0..3}
-  const bool of32 = P.out_f32 != 0;
-  const int OSZ = of32 ? 4 : SZ;
-  const int crow = BN * OSZ + 16;
-  float ssum[NT][4], ssq[NT][4];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int ch = col0 + wn * WTN + j * 16 + 4 * q4;
-    float bv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      bv[e] = (P.bias != nullptr && ch + e < P.Cn) ? P.bias[ch + e] : 0.f;
-      ssum[j][e] = 0.f;
-      ssq[j][e] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int r = wm * WTM + i * 16 + r16;
-      const bool rv = sRow[2 * r + 1] >= 0;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = acc[j][i][e] + bv[e];
-        if (rv) { ssum[j][e] += v[e]; ssq[j][e] += v[e] * v[e]; }
-      }
-      char* cp = smem + r * crow + (wn * WTN + j * 16 + 4 * q4) * OSZ;
-      if (of32 || SZ == 4) {
-        *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-      } else {
-        *reinterpret_cast<u32x2*>(cp) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-      }
-    }
-  }
-  if (P.stats != nullptr) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a = ssum[j][e], b = ssq[j][e];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        if (r16 == 0) {
-          const int c = wn * WTN + j * 16 + 4 * q4 + e;
-          sStats[(wm * 2 + 0) * BN + c] = a;
-          sStats[(wm * 2 + 1) * BN + c] = b;
-        }
-      }
-  }
-  __syncthreads();
-  if (P.stats != nullptr && tid < 2 * BN) {
-    const int which = tid / BN, c = tid % BN;
-    float a = 0.f;
-#pragma unroll
-    for (int m = 0; m < WGM; ++m) a += sStats[(m * 2 + which) * BN + c];
-    const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + (int64_t)blockIdx.z * P.tiles + tile;
-    P.stats[(slot_t * 2 + which) * P.stats_ld + col0 + c] = a;
-  }
-  {
-    const int EPO = 16 / OSZ;               // output elements per 16-byte chunk
-    const int cpr = BN / EPO;                // chunks per tile row
-    const bool af32 = P.add_f32 != 0;
-    const int ASZ = af32 ? 4 : SZ;
-    for (int idx = tid; idx < BM * cpr; idx += 256) {
-      const int r = idx / cpr, cc = idx - r * cpr;
-      const int ch = col0 + cc * EPO;
-      const int z = sRow[2 * r + 1];
-      if (z < 0 || ch >= P.Cn_store) continue;
-      const int xy = sRow[2 * r];
-      const int64_t vox = (((int64_t)n * P.Xo + (xy & 0xffff) * P.sout + K.ox) * P.Yo + (xy >> 16) * P.sout + K.oy) * P.Zo +
-                          z * P.sout + K.oz;
-      const char* cp = smem + r * crow + cc * 16;
-      char* op = P.out + (vox * P.o_ld + ch) * OSZ;
-      if (P.add == nullptr) {
-        *reinterpret_cast<u32x4*>(op) = *reinterpret_cast<const u32x4*>(cp);
-      } else {
-        float v[8], a[8];
-        load_n_as_float(cp, of32 || SZ == 4, EPO, v);
-        load_n_as_float(P.add + (vox * P.add_ld + ch) * ASZ, af32 || SZ == 4, EPO, a);
-        for (int e = 0; e < EPO; ++e) v[e] += a[e];
-        if (of32 || SZ == 4) store_chunk<float>(op, v);
-        else store_chunk<BF16>(op, v);
-      }
-    }
-  }
+  conv_epilogue<T, BM, BN, WGM, WGN>(P, K, smem, sStats, sRow, acc, n, tile, (int)blockIdx.z, col0);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN>
@@ -368,16 +257,34 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   a.out_f32 = d->out_f32; a.add_f32 = d->add_f32;
   a.stats_ld = d->stats_ld; a.stats_tiles = d->stats_tiles; a.stats_tile0 = d->stats_tile0;
   for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
+  const bool halo = conv_halo_eligible(a, d->dtype, d->nclass);
   if (d->stats) {
     const int bm = ctseg_conv_tile_rows(d->Cn);
-    const int tiles = (a.rows + bm - 1) / bm;
+    const int tiles = halo ? conv_halo_tiles(a) : (a.rows + bm - 1) / bm;
     const int bn = ctseg_conv_tile_cols(d->Cn);
     CTSEG_REQUIRE(d->stats_tile0 + tiles * d->nclass <= d->stats_tiles && d->stats_ld >= ((d->Cn + bn - 1) / bn) * bn,
                   "conv_igemm: stats partial layout (need stats_ld >= roundup(Cn, tile cols))");
   }
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == CTSEG_F32) launch_dtype<float>(a, smallc, d->nclass, st);
+  if (halo) launch_conv_halo(a, d->dtype, st);
+  else if (d->dtype == CTSEG_F32) launch_dtype<float>(a, smallc, d->nclass, st);
   else launch_dtype<BF16>(a, smallc, d->nclass, st);
   CTSEG_LAUNCH_CHECK("conv_igemm");
   return 0;
+}
+
+static void fill_args(const ctseg_conv_desc* d, ConvKArgs& a) {
+  a.in = (const char*)d->in; a.N = d->N; a.Xi = d->Xi; a.Yi = d->Yi; a.Zi = d->Zi; a.Xr = d->Xr; a.Yr = d->Yr; a.Zr = d->Zr;
+  a.Cg = d->Cg; a.Cn = d->Cn; a.g_ld = d->g_ld; a.sin = d->sin; a.sout = d->sout; a.rows = d->Xr * d->Yr * d->Zr;
+  for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
+}
+
+// tiles per sample (all classes) a pass with this geometry writes InstanceNorm partials for
+extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
+  if (d == nullptr || d->nclass < 1) return -1;
+  ConvKArgs a;
+  fill_args(d, a);
+  if (conv_halo_eligible(a, d->dtype, d->nclass)) return conv_halo_tiles(a);
+  const int bm = ctseg_conv_tile_rows(d->Cn);
+  return ((a.rows + bm - 1) / bm) * d->nclass;
 }

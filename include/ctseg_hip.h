@@ -69,6 +69,8 @@ typedef struct ctseg_conv_desc {
 /* Rows of the row grid / output columns one workgroup tile covers for a pass with Cn columns. */
 int ctseg_conv_tile_rows(int32_t Cn);
 int ctseg_conv_tile_cols(int32_t Cn);
+/* InstanceNorm partial tiles per sample (summed over classes) that a pass with this geometry fills: size `stats` with it */
+int ctseg_conv_num_tiles(const ctseg_conv_desc* d);
 int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream);
 
 /* Weight gradient: R[tap*Cg+a][b] = sum_rows in[row*sin+d(tap)][a] * dy[row][b]; row K=ntaps*Cg of R is

@@ -57,6 +57,25 @@ def test_conv_ops_vs_torch_cpu(golden, tag, dt, tol):
     assert rel_err(gb, g[f"{tag}_gbias"]) < tol, "bias gradient"
 
 
+@pytest.mark.parametrize("dt,tol", [(F32, 2e-5), (BF16, 2.5e-2)])
+@pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 12, 16, 24)), (16, 16, (1, 9, 11, 13)), (16, 10, (1, 8, 8, 8)),
+                                            (8, 8, (1, 4, 8, 8)), (32, 16, (1, 5, 8, 4))])
+def test_halo_kernel_layers_vs_torch_cpu(cin, cout, shape, dt, tol):
+    """3x3x3 stride-1 layers that take the LDS-halo kernel (Cg*size in {32,64} bytes, Cn <= 32), incl. ragged tiles."""
+    torch.manual_seed(cin * 100 + cout)
+    mod = torch.nn.Conv3d(cin, cout, 3, 1, 1)
+    x = torch.randn(shape[0], cin, *shape[1:])
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yy, gx, gw, gb = run_conv_module(mod, x, gy, dt, DEV)
+    assert rel_err(yy, y.detach()) < tol, "forward"
+    assert rel_err(gx, xr.grad) < tol, "input gradient"
+    assert rel_err(gw, mod.weight.grad) < tol, "weight gradient"
+    assert rel_err(gb, mod.bias.grad) < tol, "bias gradient"
+
+
 @pytest.mark.parametrize("dt,tol", [(F32, 1e-5), (BF16, 2e-2)])
 def test_instnorm_prelu_fwd_bwd(golden, dt, tol):
     """conv-epilogue statistics -> finalize -> apply, and the 3-kernel backward, against InstanceNorm3d+PReLU."""
