@@ -72,6 +72,7 @@ _SIGS = {
     "ctseg_conv_num_tiles": (C.c_int, [C.POINTER(ConvDesc)]),
     "ctseg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "ctseg_wgrad_tile_cols": (C.c_int, [_i32]),
+    "ctseg_conv_wgrad_slabs": (C.c_int, [C.POINTER(WgradDesc)]),
     "ctseg_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
     "ctseg_conv_wgrad_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ctseg_gather_cast": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp]),

@@ -333,9 +333,8 @@ class GemmLayer:
         kpad_w, cn_pad = rup(self.T * cg + 1, 128), rup(cn, bnw)
         nwg = (kpad_w // 128) * (cn_pad // bnw) * N
         splits = max(1, min(math.ceil(2048 / nwg), math.ceil(rows / 512), 1024))
-        ws = torch.zeros(N * splits * kpad_w * cn_pad, dtype=torch.float32, device=plan.device)
         d = nat.WgradDesc()
-        d.in_, d.dy, d.ws, d.dtype = gathered.ptr(), dyy.ptr(), ws.data_ptr(), plan.dt
+        d.in_, d.dy, d.dtype = gathered.ptr(), dyy.ptr(), plan.dt
         d.N, d.Xi, d.Yi, d.Zi = gathered.dims
         d.Xr, d.Yr, d.Zr = rowgrid
         d.Cg, d.Cn, d.g_ld, d.d_ld, d.sin = cg, cn, gathered.ld, dyy.ld, sin
@@ -343,17 +342,21 @@ class GemmLayer:
         for j, (_, off) in enumerate(self.wg_taps):
             d.taps[j] = off
         d.splits, d.kpad_w, d.cn_pad = splits, kpad_w, cn_pad
+        nslabs = lib.ctseg_conv_wgrad_slabs(d)     # N*splits, or one per persistent workgroup (LDS-halo kernel)
+        assert nslabs > 0
+        ws = torch.zeros(nslabs * kpad_w * cn_pad, dtype=torch.float32, device=plan.device)
+        d.ws = ws.data_ptr()
         plan.emit("ctseg_conv_wgrad", d, keep=(gathered, dyy, ws))
         if not self.transposed:
             col0 = 0
             for w, b, cout in self.parts:
-                plan.emit("ctseg_conv_wgrad_reduce", ws.data_ptr(), N * splits, kpad_w, cn_pad, A, cg, self.T, col0, cout,
+                plan.emit("ctseg_conv_wgrad_reduce", ws.data_ptr(), nslabs, kpad_w, cn_pad, A, cg, self.T, col0, cout,
                           st.g_ptr(w), st.g_ptr(b) if b is not None else None)
                 col0 += cout
         else:
             w, b, cout = self.parts[0]
             # R[(t, co)][ci] -> W_T[ci][co][t]; the bias gradient of a transposed conv is sum over dOut: separate pass
-            plan.emit("ctseg_conv_wgrad_reduce", ws.data_ptr(), N * splits, kpad_w, cn_pad, A, cg, self.T, 0, cn,
+            plan.emit("ctseg_conv_wgrad_reduce", ws.data_ptr(), nslabs, kpad_w, cn_pad, A, cg, self.T, 0, cn,
                       st.g_ptr(w), None)
             if b is not None:
                 plan.emit_colsum(dy, st.g_ptr(b))

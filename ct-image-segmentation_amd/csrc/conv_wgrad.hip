@@ -239,22 +239,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int nslabs, int kpad_w, int cn_pad, int A, int AS, int T,
                                     int col0, int nb, float* __restrict__ dw, float* __restrict__ db) {
-  // one thread per (k, b): consecutive threads walk b (contiguous in the slab)
+  // block = 32 (k,b) elements x 8 strided sub-sums over the slabs, combined in fixed order (deterministic);
+  // consecutive threads walk b (contiguous in the slab)
+  __shared__ float s_part[8][32];
   const int64_t total = (int64_t)(T * AS + 1) * nb;
   const int64_t slab = (int64_t)kpad_w * cn_pad;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i / nb), b = (int)(i - (int64_t)k * nb);
-    const float* p = ws + (int64_t)k * cn_pad + col0 + b;
+  const int el = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  for (int64_t base = (int64_t)blockIdx.x * 32; base < total; base += (int64_t)gridDim.x * 32) {
+    const int64_t i = base + el;
+    int k = 0, b = 0;
     float s = 0.f;
-    for (int q = 0; q < nslabs; ++q) s += p[q * slab];
-    if (k == T * AS) {
-      if (db != nullptr) db[b] = s;
-    } else {
-      const int t = k / AS, a = k - t * AS;
-      if (a < A) dw[((int64_t)b * A + a) * T + t] = s;
+    if (i < total) {
+      k = (int)(i / nb);
+      b = (int)(i - (int64_t)k * nb);
+      const float* p = ws + (int64_t)k * cn_pad + col0 + b;
+      for (int q = sub; q < nslabs; q += 8) s += p[q * slab];
     }
+    s_part[sub][el] = s;
+    __syncthreads();
+    if (sub == 0 && i < total) {
+      float t8 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t8 += s_part[q][el];
+      if (k == T * AS) {
+        if (db != nullptr) db[b] = t8;
+      } else {
+        const int t = k / AS, a = k - t * AS;
+        if (a < A) dw[((int64_t)b * A + a) * T + t] = t8;
+      }
+    }
+    __syncthreads();
   }
 }
+
+bool wgrad_halo_eligible(const ctseg_wgrad_desc* d);
+int wgrad_halo_slabs(const ctseg_wgrad_desc* d);
+void launch_wgrad_halo(const ctseg_wgrad_desc* d, hipStream_t st);
 
 template <typename T, bool SMALLC> static void launch_wgrad(const WgradKArgs& a, hipStream_t st) {
   const int bnw = ctseg_wgrad_tile_cols(a.Cn);
@@ -271,6 +291,13 @@ using namespace ctseg;
 
 extern "C" int ctseg_wgrad_tile_cols(int32_t Cn) { return Cn <= 16 ? 16 : Cn <= 32 ? 32 : Cn <= 64 ? 64 : 128; }
 
+// number of fp32 slabs [kpad_w][cn_pad] a ctseg_conv_wgrad call with this descriptor writes into `ws`
+extern "C" int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d) {
+  if (d == nullptr) return -1;
+  if (wgrad_halo_eligible(d)) return wgrad_halo_slabs(d);
+  return d->N * d->splits;
+}
+
 extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
   CTSEG_REQUIRE(d != nullptr && d->in && d->dy && d->ws, "conv_wgrad: null pointer");
   CTSEG_REQUIRE(d->dtype == CTSEG_F32 || d->dtype == CTSEG_BF16, "conv_wgrad: bad dtype");
@@ -280,6 +307,12 @@ extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
   CTSEG_REQUIRE(d->ntaps >= 1 && d->ntaps <= CTSEG_MAX_TAPS && d->splits >= 1, "conv_wgrad: ntaps/splits");
   const int bnw = ctseg_wgrad_tile_cols(d->Cn);
   const int ktot = d->ntaps * d->Cg;
+  if (wgrad_halo_eligible(d)) {
+    CTSEG_REQUIRE(d->kpad_w >= ktot + 16 && d->cn_pad >= ((d->Cn + 15) / 16) * 16, "conv_wgrad: slab too small for the halo kernel");
+    launch_wgrad_halo(d, (hipStream_t)stream);
+    CTSEG_LAUNCH_CHECK("conv_wgrad_halo");
+    return 0;
+  }
   CTSEG_REQUIRE(d->kpad_w % 128 == 0 && d->kpad_w >= ktot + 1, "conv_wgrad: kpad_w %d (K=%d)", d->kpad_w, ktot);
   CTSEG_REQUIRE(d->cn_pad % bnw == 0 && d->cn_pad >= d->Cn, "conv_wgrad: cn_pad %d", d->cn_pad);
   WgradKArgs a;
@@ -310,8 +343,8 @@ extern "C" int ctseg_conv_wgrad_reduce(const float* ws, int32_t nslabs, int32_t 
                                        int32_t T, int32_t col0, int32_t nb, float* dw, float* db, void* stream) {
   CTSEG_REQUIRE(ws && dw && nslabs >= 1 && A <= AS && T * AS + 1 <= kpad_w && col0 + nb <= cn_pad, "wgrad_reduce: bad arguments");
   const int64_t total = (int64_t)(T * AS + 1) * nb;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = (int)((total + 31) / 32);
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws, nslabs, kpad_w, cn_pad, A, AS, T,
                      col0, nb, dw, db);
   CTSEG_LAUNCH_CHECK("wgrad_reduce");

@@ -1,0 +1,242 @@
+// LDS-halo weight-gradient kernel (bf16) for 3x3x3 stride-1 layers with few channels (gfx950).
+//
+//   R[tap*Cg + a][b] = sum_voxels x[voxel + d(tap)][a] * dy[voxel][b],   R[27*Cg][b] = sum_voxels dy[voxel][b]
+//
+// The generic split-K kernel re-gathers x once per 128 K-rows (27x through L2 for a 3x3x3 layer).  Here a persistent
+// workgroup stages the 6x10x10 halo of x and the 4x8x8 tile of dy ONCE per tile (double-buffered), and the four waves
+// split the 27 taps (+ one all-ones pseudo tap = bias gradient): wave w owns taps w, w+4, ... and keeps their
+// [Cg x Cn] fp32 accumulators in registers across ALL of the workgroup's tiles; dy fragments are read once per
+// 32-voxel k-step and reused for the wave's 7 taps.  Both MFMA operands contract over voxels, the slow axis of the
+// channels-last tensors: ds_read_b64_tr_b16 transposes 4 voxels x 16 channels per 16-lane group; the LDS images are
+// planes of 16 channels (32 B per voxel) and a k-step is 4 z-rows of 8 voxels, so each 32-lane half reads 8
+// contiguous 32-byte rows (256 B): bank-conflict free.  One fp32 slab per workgroup -> ctseg_conv_wgrad_reduce.
+#include "ctseg_dev.h"
+
+namespace ctseg {
+
+struct WgradHaloArgs {
+  const char* in;
+  const char* dy;
+  float* ws;
+  int N, X, Y, Z, Cg, g_ld, d_ld;
+  int kpad_w, cn_pad;
+  int tiles, txn, tyn, tzn;   // tiles per sample and per axis
+  int delta[28];              // halo voxel delta of each tap (in 32-byte rows), entry 27 unused
+};
+
+constexpr int WH_HV = 600, WH_TV = 256;
+
+template <int VB, int DBY>
+__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArgs P, int total_tiles) {
+  constexpr int PA = VB / 32, PB = DBY / 32;
+  constexpr int XBYTES = PA * WH_HV * 32, DBYTES = PB * WH_TV * 32, BUF = XBYTES + DBYTES;
+  constexpr int XCH = WH_HV * (VB / 16), DCH = WH_TV * (DBY / 16);
+  constexpr int JX = (XCH + 255) / 256, JD = (DCH + 255) / 256;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef s16x4 __attribute__((address_space(3)))* lds_s16x4;
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tap selection stays on the scalar unit
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int tq = r16 >> 2, tp = r16 & 3;
+
+  u32x4 rx[JX], rd[JD];
+  auto origin = [&](int t, int& n, int& x0, int& y0, int& z0) {
+    n = t / P.tiles;
+    int r = t - n * P.tiles;
+    const int tz = r % P.tzn; r /= P.tzn;
+    const int ty = r % P.tyn; const int tx = r / P.tyn;
+    x0 = tx * 4; y0 = ty * 8; z0 = tz * 8;
+  };
+  auto gload = [&](int t) {
+    int n, x0, y0, z0;
+    origin(t, n, x0, y0, z0);
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const int idx = tid + j * 256;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx < XCH) {
+        const int c = idx % (VB / 16), hv = idx / (VB / 16);
+        const int hx = hv / 100, rem = hv - hx * 100, hy = rem / 10, hz = rem - hy * 10;
+        const int xi = x0 - 1 + hx, yi = y0 - 1 + hy, zi = z0 - 1 + hz;
+        if ((unsigned)xi < (unsigned)P.X && (unsigned)yi < (unsigned)P.Y && (unsigned)zi < (unsigned)P.Z) {
+          const int64_t vox = (((int64_t)n * P.X + xi) * P.Y + yi) * P.Z + zi;
+          v = *reinterpret_cast<const u32x4*>(P.in + (vox * P.g_ld + c * 8) * 2);
+        }
+      }
+      rx[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+      const int idx = tid + j * 256;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx < DCH) {
+        const int c = idx % (DBY / 16), tv = idx / (DBY / 16);
+        const int xi = x0 + (tv >> 6), yi = y0 + ((tv >> 3) & 7), zi = z0 + (tv & 7);
+        if (xi < P.X && yi < P.Y && zi < P.Z) {
+          const int64_t vox = (((int64_t)n * P.X + xi) * P.Y + yi) * P.Z + zi;
+          v = *reinterpret_cast<const u32x4*>(P.dy + (vox * P.d_ld + c * 8) * 2);
+        }
+      }
+      rd[j] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+    char* xs = smem + buf * BUF;
+    char* ds = xs + XBYTES;
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const int idx = tid + j * 256;
+      if (idx < XCH) {
+        const int c = idx % (VB / 16), hv = idx / (VB / 16);
+        *reinterpret_cast<u32x4*>(xs + (c >> 1) * (WH_HV * 32) + hv * 32 + (c & 1) * 16) = rx[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+      const int idx = tid + j * 256;
+      if (idx < DCH) {
+        const int c = idx % (DBY / 16), tv = idx / (DBY / 16);
+        *reinterpret_cast<u32x4*>(ds + (c >> 1) * (WH_TV * 32) + tv * 32 + (c & 1) * 16) = rd[j];
+      }
+    }
+  };
+
+  f32x4 acc[7][PA][PB];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int a = 0; a < PA; ++a)
+#pragma unroll
+      for (int b = 0; b < PB; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this lane's voxel inside a k-step for the two transposed reads: y-row 2r + (q4>>1), z = 4*(q4&1) + tq
+  const int lz = 4 * (q4 & 1) + tq, ly = q4 >> 1;
+  s16x8 ones;
+  {
+    const short o = (r16 == 0) ? (short)0x3f80 : (short)0;
+    ones = s16x8{o, o, o, o, o, o, o, o};
+  }
+
+  int t = blockIdx.x, cur = 0;
+  if (t < total_tiles) {
+    gload(t);
+    sstore(0);
+  }
+  __syncthreads();
+  for (; t < total_tiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    if (tn < total_tiles) gload(tn);
+    const char* xs = smem + cur * BUF;
+    const char* ds = xs + XBYTES;
+#pragma unroll 2
+    for (int s = 0; s < 8; ++s) {
+      const int x = s >> 1, yb = 4 * (s & 1);
+      // dy fragments of this k-step (shared by the wave's 7 taps)
+      bf16x8 df[PB];
+#pragma unroll
+      for (int b = 0; b < PB; ++b) {
+        const char* p0 = ds + b * (WH_TV * 32) + (((x * 8) + (yb + ly)) * 8 + lz) * 32 + tp * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 2 * 8 * 32));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        df[b] = __builtin_bit_cast(bf16x8, v);
+      }
+      const int hbase = (((x + 1) * 10) + (yb + ly + 1)) * 10 + (lz + 1);
+#pragma unroll
+      for (int ti = 0; ti < 7; ++ti) {
+        const int tap = wave + 4 * ti;
+        if (tap < 27) {
+          const int h = hbase + P.delta[tap];
+#pragma unroll
+          for (int a = 0; a < PA; ++a) {
+            const char* p0 = xs + a * (WH_HV * 32) + h * 32 + tp * 8;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 2 * 10 * 32));
+            const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const bf16x8 af = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+            for (int b = 0; b < PB; ++b) acc[ti][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, df[b], acc[ti][a][b], 0, 0, 0);
+          }
+        } else {  // pseudo tap 27: x == 1 on channel row 0 -> row 0 of the tile accumulates sum(dy) (bias gradient)
+#pragma unroll
+          for (int b = 0; b < PB; ++b)
+            acc[ti][0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), df[b], acc[ti][0][b], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (tn < total_tiles) sstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- one slab per workgroup: lane holds column c16 = dy channel, rows 4*q4 + e = x channel ------------------------
+  float* slab = P.ws + (int64_t)blockIdx.x * P.kpad_w * P.cn_pad;
+#pragma unroll
+  for (int ti = 0; ti < 7; ++ti) {
+    const int tap = wave + 4 * ti;
+#pragma unroll
+    for (int a = 0; a < PA; ++a) {
+      if (tap == 27 && a > 0) continue;
+#pragma unroll
+      for (int b = 0; b < PB; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = tap * P.Cg + a * 16 + 4 * q4 + e;
+          if (row < P.kpad_w) slab[(int64_t)row * P.cn_pad + b * 16 + r16] = acc[ti][a][b][e];
+        }
+    }
+  }
+}
+
+bool wgrad_halo_eligible(const ctseg_wgrad_desc* d) {
+  if (d->dtype != CTSEG_BF16 || d->ntaps != 27 || d->sin != 1) return false;
+  const int vb = d->Cg * 2, db = ((d->Cn + 15) / 16) * 32;
+  if (!(vb == 32 || vb == 64) || !(db == 32 || db == 64)) return false;
+  if (d->Xr != d->Xi || d->Yr != d->Yi || d->Zr != d->Zi || d->Zr < 4) return false;
+  if (d->g_ld % 8 || d->d_ld % 8 || d->d_ld < db / 2 || ((uintptr_t)d->in % 16) || ((uintptr_t)d->dy % 16)) return false;
+  if (d->cn_pad < db / 2) return false;
+  for (int j = 0; j < 27; ++j)
+    for (int s = 0; s < 24; s += 8) {
+      const int v = (int)(int8_t)((d->taps[j] >> s) & 0xff);
+      if (v < -1 || v > 1) return false;
+    }
+  return true;
+}
+
+static int wgrad_halo_grid(const ctseg_wgrad_desc* d) {
+  const int tiles = ((d->Xr + 3) / 4) * ((d->Yr + 7) / 8) * ((d->Zr + 7) / 8) * d->N;
+  const int vb = d->Cg * 2, db = ((d->Cn + 15) / 16) * 32;
+  const int per_cu = (vb + db <= 64) ? 2 : 1;
+  int g = 256 * per_cu;
+  return g < tiles ? g : tiles;
+}
+
+int wgrad_halo_slabs(const ctseg_wgrad_desc* d) { return wgrad_halo_grid(d); }
+
+void launch_wgrad_halo(const ctseg_wgrad_desc* d, hipStream_t st) {
+  WgradHaloArgs a;
+  a.in = (const char*)d->in; a.dy = (const char*)d->dy; a.ws = d->ws;
+  a.N = d->N; a.X = d->Xr; a.Y = d->Yr; a.Z = d->Zr; a.Cg = d->Cg; a.g_ld = d->g_ld; a.d_ld = d->d_ld;
+  a.kpad_w = d->kpad_w; a.cn_pad = d->cn_pad;
+  a.txn = (d->Xr + 3) / 4; a.tyn = (d->Yr + 7) / 8; a.tzn = (d->Zr + 7) / 8;
+  a.tiles = a.txn * a.tyn * a.tzn;
+  for (int j = 0; j < 28; ++j) {
+    int v = 0;
+    if (j < 27) {
+      const int tp = d->taps[j];
+      v = ((int)(int8_t)(tp & 0xff) * 10 + (int)(int8_t)((tp >> 8) & 0xff)) * 10 + (int)(int8_t)((tp >> 16) & 0xff);
+    }
+    a.delta[j] = v;
+  }
+  const int total = a.tiles * d->N, grid = wgrad_halo_grid(d);
+  const int vb = d->Cg * 2, db = ((d->Cn + 15) / 16) * 32;
+  if (vb == 32 && db == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<32, 32>), dim3(grid), dim3(256), 0, st, a, total);
+  else if (vb == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<32, 64>), dim3(grid), dim3(256), 0, st, a, total);
+  else if (db == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<64, 32>), dim3(grid), dim3(256), 0, st, a, total);
+  else hipLaunchKernelGGL((conv_wgrad_halo_kernel<64, 64>), dim3(grid), dim3(256), 0, st, a, total);
+}
+
+}  // namespace ctseg

@@ -91,6 +91,9 @@ typedef struct ctseg_wgrad_desc {
 } ctseg_wgrad_desc;
 
 int ctseg_wgrad_tile_cols(int32_t Cn);
+/* slabs this descriptor makes ctseg_conv_wgrad write (N*splits, or one per persistent workgroup of the LDS-halo
+ * kernel that few-channel 3x3x3 stride-1 bf16 layers take): size `ws` and call the reduce with it. `ws`/`dy`/`in` may be NULL here */
+int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d);
 int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream);
 /* dw[(b*A + a)*T + t] = sum_s ws[s][t*Astride + a][col0 + b]  for a < A, b < nb;
  * db[b] = sum_s ws[s][T*Astride][col0+b] (db may be NULL).  Astride = the pass's (padded) Cg. */
