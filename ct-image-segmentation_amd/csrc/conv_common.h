@@ -106,25 +106,57 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
     const int cpr = BN / EPO;                // chunks per tile row
     const bool af32 = P.add_f32 != 0;
     const int ASZ = af32 ? 4 : SZ;
-    for (int idx = tid; idx < BM * cpr; idx += 256) {
-      const int r = idx / cpr, cc = idx - r * cpr;
-      const int ch = col0 + cc * EPO;
-      const int z = sRow[2 * r + 1];
-      if (z < 0 || ch >= P.Cn_store) continue;
-      const int xy = sRow[2 * r];
-      const int64_t vox = (((int64_t)n * P.Xo + (xy & 0xffff) * P.sout + K.ox) * P.Yo + (xy >> 16) * P.sout + K.oy) * P.Zo +
-                          z * P.sout + K.oz;
-      const char* cp = smem + r * crow + cc * 16;
-      char* op = P.out + (vox * P.o_ld + ch) * OSZ;
-      if (P.add == nullptr) {
-        *reinterpret_cast<u32x4*>(op) = *reinterpret_cast<const u32x4*>(cp);
-      } else {
-        float v[8], a[8];
-        load_n_as_float(cp, of32 || SZ == 4, EPO, v);
-        load_n_as_float(P.add + (vox * P.add_ld + ch) * ASZ, af32 || SZ == 4, EPO, a);
-        for (int e = 0; e < EPO; ++e) v[e] += a[e];
-        if (of32 || SZ == 4) store_chunk<float>(op, v);
-        else store_chunk<BF16>(op, v);
+    // batches of 4 chunks per thread: all addend loads of a batch are issued before the first use, so their
+    // latency overlaps (one exposed round trip per batch instead of one per chunk)
+    constexpr int UN = 4;
+    const int nadd = (af32 || SZ == 4) ? EPO * 4 : EPO * 2;   // addend bytes per chunk: 8, 16 or 32
+    for (int base = tid; base < BM * cpr; base += 256 * UN) {
+      char* op[UN];
+      const char* cp[UN];
+      u32x4 a0[UN], a1[UN];
+      bool ok[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = base + u * 256;
+        const int r = (idx < BM * cpr) ? idx / cpr : 0, cc = idx - r * cpr;
+        const int ch = col0 + cc * EPO;
+        const int z = sRow[2 * r + 1];
+        ok[u] = idx < BM * cpr && z >= 0 && ch < P.Cn_store;
+        const int xy = sRow[2 * r];
+        const int64_t vox = (((int64_t)n * P.Xo + (xy & 0xffff) * P.sout + K.ox) * P.Yo + (xy >> 16) * P.sout + K.oy) * P.Zo +
+                            z * P.sout + K.oz;
+        cp[u] = smem + r * crow + cc * 16;
+        op[u] = P.out + (vox * P.o_ld + ch) * OSZ;
+        a0[u] = u32x4{0u, 0u, 0u, 0u};
+        a1[u] = a0[u];
+        if (ok[u] && P.add != nullptr) {
+          const char* ap = P.add + (vox * P.add_ld + ch) * ASZ;
+          if (nadd == 8) { const u32x2 t = *reinterpret_cast<const u32x2*>(ap); a0[u][0] = t[0]; a0[u][1] = t[1]; }
+          else {
+            a0[u] = *reinterpret_cast<const u32x4*>(ap);
+            if (nadd == 32) a1[u] = *reinterpret_cast<const u32x4*>(ap + 16);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (!ok[u]) continue;
+        if (P.add == nullptr) {
+          *reinterpret_cast<u32x4*>(op[u]) = *reinterpret_cast<const u32x4*>(cp[u]);
+        } else {
+          float v[8], a[8];
+          load_n_as_float(cp[u], of32 || SZ == 4, EPO, v);
+          if (af32 || SZ == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = __uint_as_float(a0[u][e]); a[4 + e] = __uint_as_float(a1[u][e]); }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[2 * e] = bf2f(a0[u][e] & 0xffffu); a[2 * e + 1] = bf2f(a0[u][e] >> 16); }
+          }
+          for (int e = 0; e < EPO; ++e) v[e] += a[e];
+          if (of32 || SZ == 4) store_chunk<float>(op[u], v);
+          else store_chunk<BF16>(op[u], v);
+        }
       }
     }
   }

@@ -3,14 +3,19 @@
 // The full- and half-resolution layers of the reference's U-Net (32->32 at 256x256x24, the 10->10 logits conv
 // at 512x512x48 and their input gradients) are HBM-bound: per output voxel the generic kernel re-gathers 27
 // neighbours through the vector-memory path.  Here a persistent workgroup keeps ALL packed weights in LDS, stages
-// the (4+2)x(8+2)x(8+2) input halo of a 4x8x8 output tile ONCE (16-byte chunks, zero fill at the border),
-// double-buffered against the previous tile's MFMAs, and reads every tap's operand from LDS: 27x reuse.
+// the (4+2)x(8+2)x(8+2) input halo of a 4x8x8 output tile ONCE (16-byte chunks, zero fill at the border) two
+// tiles ahead of the MFMAs, and reads every tap's operand from LDS: 27x reuse.
 //
 // LDS image of the halo: one plane per 16-byte channel chunk, [plane][600 voxels][16 B].  600*16 B = 8 slots
 // (mod 16), and inside each 2x8 (y,z) patch of 16 voxels the lane<->voxel map below is chosen so that every
 // ds_read_b128 lane group of an MFMA operand hits 16 distinct 16-byte slots for every tap: conflict free
-// (checked exhaustively on the host).  Epilogue = conv_common.h (bias, InstanceNorm partials,
-// addend, channels-last stores), so both kernels are interchangeable behind ctseg_conv_igemm.
+// (checked exhaustively on the host).
+//
+// These layers do ~430 MACs per output value, so per-tile bookkeeping is what has to be cheap: all gather / store
+// offsets are per-thread constants computed once (only a scalar tile base changes), and the epilogue stores straight
+// from the accumulators — with the weight tile as first MFMA operand a lane owns 4 consecutive channels of one voxel
+// (8 B bf16 / 16 B fp32) — + bias, InstanceNorm partial sums, optional addend.  Same contract as conv_igemm.hip, so
+// ctseg_conv_igemm picks the kernel transparently.
 #include "conv_common.h"
 
 namespace ctseg {
@@ -32,9 +37,7 @@ template <int VB, int NT> struct HaloCfg {
   static constexpr int KC = (27 * VB + 63) / 64;   // 64-byte K chunks
   static constexpr int NSTG = (KC + 1) / 2;        // 128-byte weight stages
   static constexpr int WBYTES = NSTG * BN * 128;
-  static constexpr int CS = 256 * (BN * 4 + 16);
-  static constexpr int BUF = HALO > CS ? HALO : CS;
-  static constexpr int TOTAL = WBYTES + 2 * BUF + 4 * 2 * BN * 4 + 256 * 8 + 32 * 4;
+  static constexpr int TOTAL = WBYTES + 2 * HALO + 4 * 2 * BN * 4 + 32 * 4;
 };
 
 template <typename T, int VB, int NT>
@@ -47,9 +50,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
   __shared__ __attribute__((aligned(16))) char smem[CF::TOTAL];
   char* const sW = smem;
   char* const sH = smem + CF::WBYTES;
-  float* const sStats = reinterpret_cast<float*>(sH + 2 * CF::BUF);
-  int* const sRow = reinterpret_cast<int*>(sH + 2 * CF::BUF + 4 * 2 * BN * 4);
-  int* const sDelta = sRow + 512;
+  float* const sStats = reinterpret_cast<float*>(sH + 2 * CF::HALO);
+  int* const sDelta = reinterpret_cast<int*>(sH + 2 * CF::HALO + 4 * 2 * BN * 4);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q4 = lane >> 4;
@@ -72,9 +74,20 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
     sDelta[tid] = d * 16;
   }
 
+  // ---- per-thread constants of the J staging slots (only the tile base changes from tile to tile) -----------------
+  const int YZ = P.Yi * P.Zi;
+  int g_byte[J], g_hxyz[J], g_lds[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int idx = tid + j * 256;
+    const int pl = (idx >> 3) % NPL, hv = (idx / (8 * NPL)) * 8 + (idx & 7);
+    const int hx = hv / (H_HY * H_HZ), rem = hv - hx * (H_HY * H_HZ);
+    const int hy = rem / H_HZ, hz = rem - hy * H_HZ;
+    g_byte[j] = (((hx - 1) * YZ + (hy - 1) * P.Zi + (hz - 1)) * P.g_ld + pl * EPC) * SZ;
+    g_hxyz[j] = (idx < NCH) ? (hx | (hy << 8) | (hz << 16)) : 0x7f7f7f;   // sentinel fails every bounds test
+    g_lds[j] = pl * H_PLANE + hv * 16;
+  }
   const int tiles_per_sample = P.tiles;
-  // chunk -> (plane, halo voxel) for this thread's J staging slots (same for every tile)
-  u32x4 rh[J];
   auto tile_origin = [&](int t, int& n, int& x0, int& y0, int& z0) {
     n = t / tiles_per_sample;
     int r = t - n * tiles_per_sample;
@@ -82,74 +95,58 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
     const int ty = r % tyn; const int tx = r / tyn;
     x0 = tx * H_TX; y0 = ty * H_TY; z0 = tz * H_TZ;
   };
-  auto gload = [&](int t) {
+  auto gload = [&](int t, u32x4 (&rh)[J]) {
     int n, x0, y0, z0;
     tile_origin(t, n, x0, y0, z0);
+    const char* base = P.in + ((((int64_t)n * P.Xi + x0) * P.Yi + y0) * P.Zi + z0) * P.g_ld * SZ;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      const int idx = tid + j * 256;
+      const int xi = x0 - 1 + (g_hxyz[j] & 0xff), yi = y0 - 1 + ((g_hxyz[j] >> 8) & 0xff), zi = z0 - 1 + (g_hxyz[j] >> 16);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx < NCH) {
-        const int pl = (idx >> 3) % NPL, hv = (idx / (8 * NPL)) * 8 + (idx & 7);
-        const int hx = hv / (H_HY * H_HZ), rem = hv - hx * (H_HY * H_HZ);
-        const int hy = rem / H_HZ, hz = rem - hy * H_HZ;
-        const int xi = x0 - 1 + hx, yi = y0 - 1 + hy, zi = z0 - 1 + hz;
-        if ((unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi) {
-          const int64_t vox = (((int64_t)n * P.Xi + xi) * P.Yi + yi) * P.Zi + zi;
-          v = *reinterpret_cast<const u32x4*>(P.in + (vox * P.g_ld + pl * EPC) * SZ);
-        }
-      }
+      if ((unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi)
+        v = *reinterpret_cast<const u32x4*>(base + g_byte[j]);
       rh[j] = v;
     }
   };
-  auto sstore = [&](int buf) {
-    char* h = sH + buf * CF::BUF;
+  auto sstore = [&](int buf, const u32x4 (&rh)[J]) {
+    char* h = sH + buf * CF::HALO;
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int idx = tid + j * 256;
-      if (idx < NCH) {
-        const int pl = (idx >> 3) % NPL, hv = (idx / (8 * NPL)) * 8 + (idx & 7);
-        *reinterpret_cast<u32x4*>(h + pl * H_PLANE + hv * 16) = rh[j];
-      }
-    }
+    for (int j = 0; j < J; ++j)
+      if (J * 256 == NCH || tid + j * 256 < NCH) *reinterpret_cast<u32x4*>(h + g_lds[j]) = rh[j];
   };
 
-  // lane's operand addresses: row-tile i of wave w covers x = w, y in {2i, 2i+1}, z 0..7 (permuted, see header)
+  // ---- per-lane constants of the MFMA operands and of the epilogue ---------------------------------------------------
+  // row-tile i of wave w covers x = w, y in {2i, 2i+1}, z 0..7 (permuted inside the 2x8 patch, see header)
   int pdy, pz;
   patch_voxel(r16, pdy, pz);
-  int abase[4];
+  int abase[4], ovox[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) abase[i] = ((((wave + 1) * H_HY) + (2 * i + pdy + 1)) * H_HZ + (pz + 1)) * 16;
+  for (int i = 0; i < 4; ++i) {
+    abase[i] = ((((wave + 1) * H_HY) + (2 * i + pdy + 1)) * H_HZ + (pz + 1)) * 16;
+    ovox[i] = (wave * P.Yo + 2 * i + pdy) * P.Zo + pz;       // voxel offset from the tile's first voxel
+  }
   const int aplane = (VB == 64 ? q4 : (q4 & 1)) * H_PLANE;
   const int wrow = r16 * 128, wswz = (r16 >> 1) & 7;
+  const bool of32 = P.out_f32 != 0, af32 = (P.add_f32 != 0) || SZ == 4;
+  const int OSZ = (of32 || SZ == 4) ? 4 : 2, ASZ = af32 ? 4 : 2;
+  float bias[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = col0 + j * 16 + 4 * q4 + e;
+      bias[j][e] = (P.bias != nullptr && ch < P.Cn) ? P.bias[ch] : 0.f;
+    }
 
-  int t = blockIdx.x;
-  int cur = 0;
-  if (t < total_tiles) {
-    gload(t);
-    sstore(0);
-  }
-  __syncthreads();
-  for (; t < total_tiles; t += gridDim.x) {
-    const int tn = t + gridDim.x;
-    if (tn < total_tiles) gload(tn);
+  auto compute_tile = [&](int t, int buf) {
     int n, x0, y0, z0;
     tile_origin(t, n, x0, y0, z0);
-    {  // row table of this tile (read by the epilogue after the barrier below)
-      const int r = tid, w = r >> 6, i = (r >> 4) & 3;
-      int dy, z;
-      patch_voxel(r & 15, dy, z);
-      const int x = x0 + w, y = y0 + 2 * i + dy, zz = z0 + z;
-      const bool ok = x < P.Xr && y < P.Yr && zz < P.Zr;
-      sRow[2 * r] = x | (y << 16);
-      sRow[2 * r + 1] = ok ? zz : -(1 << 24);
-    }
     f32x4 acc[NT][4];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const char* h = sH + cur * CF::BUF + aplane;
+    const char* h = sH + buf * CF::HALO + aplane;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
       int delta;
@@ -170,12 +167,119 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
 #pragma unroll
         for (int i = 0; i < 4; ++i) mma16<T>(acc[j][i], wf[j], xf[i]);
     }
-    __syncthreads();  // every wave is done with halo[cur]; sRow is visible
-    conv_epilogue<T, 256, BN, 4, 1>(P, K, sH + cur * CF::BUF, sStats, sRow, acc, n,
-                                    t - n * tiles_per_sample, 0, col0);
-    if (tn < total_tiles) sstore(cur ^ 1);
-    __syncthreads();  // halo[cur^1] complete, epilogue's LDS reads done
-    cur ^= 1;
+    // ---- epilogue straight from the accumulators: lane = (voxel of row-tile i, channels j*16 + 4*q4 .. +3) --------
+    const int64_t vb = (((int64_t)n * P.Xo + x0) * P.Yo + y0) * P.Zo + z0;
+    const bool xok = x0 + wave < P.Xr, zok = z0 + pz < P.Zr;
+    bool rv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rv[i] = xok && zok && (y0 + 2 * i + pdy < P.Yr);
+    u32x4 av[NT][4];
+    if (P.add != nullptr) {
+      const char* ab = P.add + vb * P.add_ld * ASZ;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ch = col0 + j * 16 + 4 * q4;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (rv[i] && ch < P.Cn_store) {
+            const char* ap = ab + ((int64_t)ovox[i] * P.add_ld + ch) * ASZ;
+            if (af32) v = *reinterpret_cast<const u32x4*>(ap);
+            else { const u32x2 w2 = *reinterpret_cast<const u32x2*>(ap); v[0] = w2[0]; v[1] = w2[1]; }
+          }
+          av[j][i] = v;
+        }
+    }
+    float ssum[NT][4], ssq[NT][4];
+    char* ob = P.out + vb * P.o_ld * OSZ;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ch = col0 + j * 16 + 4 * q4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ssum[j][e] = 0.f; ssq[j][e] = 0.f; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[j][i][e] + bias[j][e];
+          if (rv[i]) { ssum[j][e] += v[e]; ssq[j][e] += v[e] * v[e]; }
+        }
+        if (P.add != nullptr) {
+          if (af32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(av[j][i][e]);
+          } else {
+            v[0] += bf2f(av[j][i][0] & 0xffffu); v[1] += bf2f(av[j][i][0] >> 16);
+            v[2] += bf2f(av[j][i][1] & 0xffffu); v[3] += bf2f(av[j][i][1] >> 16);
+          }
+        }
+        if (rv[i] && ch < P.Cn_store) {
+          char* op = ob + ((int64_t)ovox[i] * P.o_ld + ch) * OSZ;
+          if (OSZ == 4) *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+          else *reinterpret_cast<u32x2*>(op) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        }
+      }
+    }
+    if (P.stats != nullptr) {   // per-(tile, channel) partial sums: 16 voxel lanes -> wave -> workgroup, one slot per tile
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = ssum[j][e], b = ssq[j][e];
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+          if (r16 == 0) {
+            const int c = j * 16 + 4 * q4 + e;
+            sStats[(wave * 2 + 0) * BN + c] = a;
+            sStats[(wave * 2 + 1) * BN + c] = b;
+          }
+        }
+      __syncthreads();
+      if (tid < 2 * BN) {
+        const int which = tid / BN, c = tid % BN;
+        const float a = sStats[(0 * 2 + which) * BN + c] + sStats[(1 * 2 + which) * BN + c] + sStats[(2 * 2 + which) * BN + c] +
+                        sStats[(3 * 2 + which) * BN + c];
+        const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + (t - n * tiles_per_sample);
+        P.stats[(slot_t * 2 + which) * P.stats_ld + col0 + c] = a;
+      }
+    }
+  };
+
+  // tile sequence of this workgroup: each XCD (blockIdx % 8 shares one) owns a contiguous range of tiles, its workgroups
+  // walk it round-robin, so the ~64 tiles in flight on one XCD are neighbours and share halos through that XCD's L2
+  const int G = gridDim.x;
+  int first, stride, last;
+  if ((G & 7) == 0) {
+    const int chunk = (total_tiles + 7) / 8, xcd = blockIdx.x & 7;
+    first = xcd * chunk + (blockIdx.x >> 3);
+    stride = G >> 3;
+    last = (xcd + 1) * chunk < total_tiles ? (xcd + 1) * chunk : total_tiles;
+  } else {
+    first = blockIdx.x; stride = G; last = total_tiles;
+  }
+  u32x4 r0[J], r1[J];
+  int ta = first, tb = first + stride;
+  if (ta < last) {
+    gload(ta, r0);
+    sstore(0, r0);
+  }
+  if (tb < last) gload(tb, r1);
+  __syncthreads();
+  while (ta < last) {
+    const int tc = tb + stride;       // tile after tb
+    if (tc < last) gload(tc, r0);
+    compute_tile(ta, 0);
+    if (tb < last) sstore(1, r1);
+    __syncthreads();                  // halo[1] complete; every wave is done reading halo[0] and the stats slots
+    if (tb >= last) break;
+    const int td = tc + stride;
+    if (td < last) gload(td, r1);
+    compute_tile(tb, 1);
+    if (tc < last) sstore(0, r0);
+    __syncthreads();
+    ta = tc;
+    tb = td;
   }
 }
 
@@ -186,6 +290,7 @@ bool conv_halo_eligible(const ConvKArgs& a, int dtype, int nclass) {
   if (!(vb == 32 || vb == 64) || a.Cn > 32) return false;
   if ((a.g_ld * SZ) % 16 != 0 || ((uintptr_t)a.in % 16) != 0) return false;
   if (a.Xr != a.Xi || a.Yr != a.Yi || a.Zr != a.Zi || a.Zr < 4) return false;
+  if ((int64_t)a.Xi * a.Yi * a.Zi * a.g_ld * SZ >= (1ll << 31)) return false;   // per-sample byte offsets are 32-bit
   for (int j = 0; j < 27; ++j) {
     const int tp = a.cls[0].taps[j];
     for (int s = 0; s < 24; s += 8) {
@@ -204,7 +309,7 @@ template <typename T, int VB, int NT> static void launch_halo(ConvKArgs& a, hipS
   const int tyn = (a.Yr + H_TY - 1) / H_TY, tzn = (a.Zr + H_TZ - 1) / H_TZ;
   a.tiles = conv_halo_tiles(a);
   const int total = a.tiles * a.N;
-  const int per_cu = HaloCfg<VB, NT>::TOTAL > 80 * 1024 ? 1 : (HaloCfg<VB, NT>::TOTAL > 52 * 1024 ? 2 : 3);
+  const int per_cu = HaloCfg<VB, NT>::TOTAL > 80 * 1024 ? 1 : (HaloCfg<VB, NT>::TOTAL > 54000 ? 2 : 3);   // 160 KiB LDS per CU
   int gx = 256 * per_cu;
   if (gx > total) gx = total;
   dim3 grid((unsigned)gx, (unsigned)((a.Cn + 16 * NT - 1) / (16 * NT)), 1);
