@@ -166,5 +166,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
 bool conv_halo_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_halo_tiles(const ConvKArgs& a);
 void launch_conv_halo(ConvKArgs& a, int dtype, hipStream_t st);
+// 8-class stride-2 "up" pass with <= 16 output channels (conv_up_halo.hip): one input tile for all parity classes
+bool conv_up_eligible(const ConvKArgs& a, int dtype, int nclass);
+int conv_up_tiles(const ConvKArgs& a);
+void launch_conv_up(ConvKArgs& a, hipStream_t st);
 
 }  // namespace ctseg

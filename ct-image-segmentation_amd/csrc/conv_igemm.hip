@@ -258,7 +258,10 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   a.stats_ld = d->stats_ld; a.stats_tiles = d->stats_tiles; a.stats_tile0 = d->stats_tile0;
   for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
   const bool halo = conv_halo_eligible(a, d->dtype, d->nclass);
-  if (d->stats) {
+  const bool up = !halo && conv_up_eligible(a, d->dtype, d->nclass);
+  if (d->stats && up) {
+    CTSEG_REQUIRE(d->stats_tile0 + conv_up_tiles(a) <= d->stats_tiles && d->stats_ld >= 16, "conv_igemm: stats partial layout (up pass)");
+  } else if (d->stats) {
     const int bm = ctseg_conv_tile_rows(d->Cn);
     const int tiles = halo ? conv_halo_tiles(a) : (a.rows + bm - 1) / bm;
     const int bn = ctseg_conv_tile_cols(d->Cn);
@@ -267,6 +270,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   if (halo) launch_conv_halo(a, d->dtype, st);
+  else if (up) launch_conv_up(a, st);
   else if (d->dtype == CTSEG_F32) launch_dtype<float>(a, smallc, d->nclass, st);
   else launch_dtype<BF16>(a, smallc, d->nclass, st);
   CTSEG_LAUNCH_CHECK("conv_igemm");
@@ -285,6 +289,8 @@ extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
   ConvKArgs a;
   fill_args(d, a);
   if (conv_halo_eligible(a, d->dtype, d->nclass)) return conv_halo_tiles(a);
+  a.out_f32 = d->out_f32; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo;
+  if (conv_up_eligible(a, d->dtype, d->nclass)) return conv_up_tiles(a);
   const int bm = ctseg_conv_tile_rows(d->Cn);
   return ((a.rows + bm - 1) / bm) * d->nclass;
 }

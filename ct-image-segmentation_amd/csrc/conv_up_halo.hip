@@ -1,0 +1,265 @@
+// LDS-halo kernel for the 8-class stride-2 "up" pass with few output channels (gfx950, bf16):
+// the top-level ConvTranspose3d(64 -> 10, k3 s2 p1 op1) of the reference's U-Net at 256x256x24 -> 512x512x48.
+//
+// Output parity class (px,py,pz) of a transposed conv is a small conv over the INPUT grid with taps at offsets
+// {0} (parity 0) or {+1, 0} (parity 1) per axis: 1+2+2+2+4+4+4+8 = 27 taps over the 8 classes.  The generic kernel
+// runs the classes as independent workgroups, each re-gathering its taps through the vector-memory path (27 gathers
+// of a 128-byte voxel per input voxel).  Here one persistent workgroup stages the (4+1)x(8+1)x(8+1) input tile ONCE,
+// keeps the packed weights of all 8 classes in LDS (27*Cg*16*2 B = 55 KB), and produces all 8 x 256 outputs of the
+// tile from LDS.  LDS halo image, lane<->voxel permutation and the register epilogue are those of conv_halo.hip
+// (same 6x10x10 slot geometry, so every ds_read_b128 operand fetch is bank-conflict free); InstanceNorm partial sums
+// are accumulated over the 8 classes in registers -> one partial slot per tile.
+#include "conv_common.h"
+
+namespace ctseg {
+
+constexpr int U_HY = 10, U_HZ = 10, U_HV = 600, U_PLANE = U_HV * 16;
+constexpr int U_FV = 5 * 9 * 9;   // voxels actually filled
+
+__device__ __forceinline__ void up_patch_voxel(int r16, int& dy, int& z) {
+  dy = (0xEF80u >> r16) & 1;
+  z = (int)((0x2104765437653210ull >> (4 * r16)) & 7ull);
+}
+
+template <int VB> struct UpCfg {
+  static constexpr int NPL = VB / 16;
+  static constexpr int HALO = NPL * U_PLANE;
+  static constexpr int WBYTES = 27 * (VB / 64) * 16 * 64;   // 27 taps x (VB/64) 64-byte chunks x 16 rows  (= 27*Cg*16*2)
+  static constexpr int TOTAL = WBYTES + 2048 + HALO + 4 * 2 * 16 * 4 + 64 * 4 + 16 * 4;
+};
+
+template <int VB>
+__global__ __launch_bounds__(256) void conv_up_halo_kernel(const ConvKArgs P, int total_tiles, int tyn, int tzn) {
+  using CF = UpCfg<VB>;
+  constexpr int NPL = CF::NPL, CPT = VB / 64;           // 64-byte K chunks per tap
+  constexpr int NCH = U_FV * NPL, J = (NCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char smem[CF::TOTAL];
+  char* const sW = smem;                                 // per class: [stages][16 rows][128 B] swizzled, stage padded
+  char* const sH = smem + CF::WBYTES + 2048;
+  float* const sStats = reinterpret_cast<float*>(sH + CF::HALO);
+  int* const sDelta = reinterpret_cast<int*>(sH + CF::HALO + 4 * 2 * 16 * 4);   // [8 classes][8 taps]
+  int* const sWst = sDelta + 64;                                                  // first weight stage of each class
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q4 = lane >> 4;
+
+  // ---- weights of all classes -> LDS; class c starts at stage wstage[c] ------------------------------------------------
+  int wstage[9];
+  wstage[0] = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) wstage[c + 1] = wstage[c] + P.cls[c].kpad * 2 / 128;
+  for (int c = 0; c < 8; ++c) {
+    const int nst = wstage[c + 1] - wstage[c];
+    for (int idx = tid; idx < 16 * nst * 8; idx += 256) {
+      const int q8 = idx & 7, row = (idx >> 3) & 15, s = idx >> 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(P.w + (P.cls[c].w_off + (int64_t)row * P.cls[c].kpad) * 2 + s * 128 + q8 * 16);
+      *reinterpret_cast<u32x4*>(sW + ((wstage[c] + s) * 16 + row) * 128 + ((q8 ^ ((row >> 1) & 7)) << 4)) = v;
+    }
+  }
+  if (tid < 9) sWst[tid] = wstage[tid];
+  if (tid < 64) {
+    const int c = tid >> 3, tp_i = tid & 7;
+    int d = 0;
+    if (tp_i < P.cls[c].ntaps) {
+      const int tp = P.cls[c].taps[tp_i];
+      d = ((int)(int8_t)(tp & 0xff) * U_HY + (int)(int8_t)((tp >> 8) & 0xff)) * U_HZ + (int)(int8_t)((tp >> 16) & 0xff);
+    }
+    sDelta[tid] = d * 16;
+  }
+
+  // ---- staging slots: the 5x9x9 voxels at halo coordinates 1..5 x 1..9 x 1..9 --------------------------------------------
+  const int YZ = P.Yi * P.Zi;
+  int g_byte[J], g_hxyz[J], g_lds[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int idx = tid + j * 256;
+    const int pl = (idx >> 3) % NPL, fv = (idx / (8 * NPL)) * 8 + (idx & 7);
+    const int fx = fv / 81, rem = fv - fx * 81, fy = rem / 9, fz = rem - fy * 9;     // offsets 0..4, 0..8, 0..8
+    g_byte[j] = ((fx * YZ + fy * P.Zi + fz) * P.g_ld + pl * 8) * 2;
+    g_hxyz[j] = (fv < U_FV) ? (fx | (fy << 8) | (fz << 16)) : 0x7f7f7f;   // 405 is not a multiple of 8: test fv, not idx
+    g_lds[j] = pl * U_PLANE + (((fx + 1) * U_HY + (fy + 1)) * U_HZ + (fz + 1)) * 16;
+  }
+  const int tiles_per_sample = P.tiles;
+  auto tile_origin = [&](int t, int& n, int& x0, int& y0, int& z0) {
+    n = t / tiles_per_sample;
+    int r = t - n * tiles_per_sample;
+    const int tz = r % tzn; r /= tzn;
+    const int ty = r % tyn; const int tx = r / tyn;
+    x0 = tx * 4; y0 = ty * 8; z0 = tz * 8;
+  };
+  u32x4 rh[J];
+  auto gload = [&](int t) {
+    int n, x0, y0, z0;
+    tile_origin(t, n, x0, y0, z0);
+    const char* base = P.in + ((((int64_t)n * P.Xi + x0) * P.Yi + y0) * P.Zi + z0) * P.g_ld * 2;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int xi = x0 + (g_hxyz[j] & 0xff), yi = y0 + ((g_hxyz[j] >> 8) & 0xff), zi = z0 + (g_hxyz[j] >> 16);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (xi < P.Xi && yi < P.Yi && zi < P.Zi) v = *reinterpret_cast<const u32x4*>(base + g_byte[j]);
+      rh[j] = v;
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+      if ((g_hxyz[j] & 0xff) != 0x7f) *reinterpret_cast<u32x4*>(sH + g_lds[j]) = rh[j];
+  };
+
+  int pdy, pz;
+  up_patch_voxel(r16, pdy, pz);
+  int abase[4], ovox[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    abase[i] = ((((wave + 1) * U_HY) + (2 * i + pdy + 1)) * U_HZ + (pz + 1)) * 16 + q4 * U_PLANE;
+    ovox[i] = ((2 * wave) * P.Yo + 2 * (2 * i + pdy)) * P.Zo + 2 * pz;     // from the tile's first OUTPUT voxel (2x0,2y0,2z0)
+  }
+  const int wrow = r16 * 128, wswz = (r16 >> 1) & 7;
+  const bool af32 = P.add_f32 != 0;
+  const int ASZ = af32 ? 4 : 2;
+  float bias[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bias[e] = (P.bias != nullptr && 4 * q4 + e < P.Cn) ? P.bias[4 * q4 + e] : 0.f;
+  const int ch = 4 * q4;
+
+  auto compute_tile = [&](int t) {
+    int n, x0, y0, z0;
+    tile_origin(t, n, x0, y0, z0);
+    const int64_t vb = (((int64_t)n * P.Xo + 2 * x0) * P.Yo + 2 * y0) * P.Zo + 2 * z0;
+    const bool xok = x0 + wave < P.Xr, zok = z0 + pz < P.Zr;
+    bool rv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rv[i] = xok && zok && (y0 + 2 * i + pdy < P.Yr);
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < 8; ++c) {
+      const ctseg_conv_class& K = P.cls[c];
+      f32x4 acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* wc = sW + sWst[c] * (16 * 128) + wrow;
+      const int nt = K.ntaps;
+#pragma unroll 1
+      for (int tp = 0; tp < nt; ++tp) {
+        const int delta = sDelta[c * 8 + tp];
+#pragma unroll
+        for (int kc = 0; kc < CPT; ++kc) {
+          const int ci = tp * CPT + kc;                 // 64-byte chunk index inside the class
+          u32x4 xf[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sH + abase[i] + kc * 4 * U_PLANE + delta);
+          const u32x4 wf = *reinterpret_cast<const u32x4*>(wc + (ci >> 1) * (16 * 128) + (((4 * (ci & 1) + q4) ^ wswz) << 4));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mma16<BF16>(acc[i], wf, xf[i]);
+        }
+      }
+      // epilogue of this class: output voxel = 2*voxel + (ox,oy,oz)
+      const int coff = (K.ox * P.Yo + K.oy) * P.Zo + K.oz;
+      char* ob = P.out + (vb + coff) * P.o_ld * 2;
+      const char* ab = (P.add != nullptr) ? P.add + (vb + coff) * P.add_ld * ASZ : nullptr;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[i][e] + bias[e];
+          if (rv[i]) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+        }
+        if (rv[i] && ch < P.Cn_store) {
+          if (ab != nullptr) {
+            const char* ap = ab + ((int64_t)ovox[i] * P.add_ld + ch) * ASZ;
+            if (af32) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap); v[0] += a4[0]; v[1] += a4[1]; v[2] += a4[2]; v[3] += a4[3]; }
+            else {
+              const u32x2 w2 = *reinterpret_cast<const u32x2*>(ap);
+              v[0] += bf2f(w2[0] & 0xffffu); v[1] += bf2f(w2[0] >> 16); v[2] += bf2f(w2[1] & 0xffffu); v[3] += bf2f(w2[1] >> 16);
+            }
+          }
+          *reinterpret_cast<u32x2*>(ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        }
+      }
+    }
+    if (P.stats != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = ssum[e], b = ssq[e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (r16 == 0) {
+          sStats[(wave * 2 + 0) * 16 + 4 * q4 + e] = a;
+          sStats[(wave * 2 + 1) * 16 + 4 * q4 + e] = b;
+        }
+      }
+      __syncthreads();
+      if (tid < 32) {
+        const int which = tid >> 4, c = tid & 15;
+        const float a = sStats[(0 * 2 + which) * 16 + c] + sStats[(1 * 2 + which) * 16 + c] + sStats[(2 * 2 + which) * 16 + c] +
+                        sStats[(3 * 2 + which) * 16 + c];
+        const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + (t - n * tiles_per_sample);
+        P.stats[(slot_t * 2 + which) * P.stats_ld + c] = a;
+      }
+    }
+  };
+
+  const int G = gridDim.x;
+  int first, stride, last;
+  if ((G & 7) == 0) {
+    const int chunk = (total_tiles + 7) / 8, xcd = blockIdx.x & 7;
+    first = xcd * chunk + (blockIdx.x >> 3);
+    stride = G >> 3;
+    last = (xcd + 1) * chunk < total_tiles ? (xcd + 1) * chunk : total_tiles;
+  } else {
+    first = blockIdx.x; stride = G; last = total_tiles;
+  }
+  // the unused -1 border of the 6x10x10 image is never read (tap offsets are 0 / +1), no need to clear it
+  int t = first;
+  if (t < last) {
+    gload(t);
+    sstore();
+  }
+  __syncthreads();
+  for (; t < last; t += stride) {
+    const int tn = t + stride;
+    if (tn < last) gload(tn);
+    compute_tile(t);
+    __syncthreads();          // every wave is done reading the halo (and the stats slots)
+    if (tn < last) sstore();
+    __syncthreads();
+  }
+}
+
+bool conv_up_eligible(const ConvKArgs& a, int dtype, int nclass) {
+  if (dtype != CTSEG_BF16 || nclass != 8 || a.sin != 1 || a.sout != 2 || a.out_f32) return false;
+  const int vb = a.Cg * 2;
+  if (!(vb == 64 || vb == 128) || a.Cn > 16) return false;
+  if ((a.g_ld % 8) != 0 || ((uintptr_t)a.in % 16) != 0) return false;
+  if (a.Xr != a.Xi || a.Yr != a.Yi || a.Zr != a.Zi || a.Zr < 4) return false;
+  if (a.Xo != 2 * a.Xr || a.Yo != 2 * a.Yr || a.Zo != 2 * a.Zr) return false;
+  if ((int64_t)a.Xi * a.Yi * a.Zi * a.g_ld * 2 >= (1ll << 31)) return false;
+  int taps = 0;
+  for (int c = 0; c < 8; ++c) {
+    const ctseg_conv_class& k = a.cls[c];
+    if (k.ntaps < 1 || k.ntaps > 8 || k.kpad != ((k.ntaps * a.Cg + 63) / 64) * 64) return false;
+    taps += k.ntaps;
+    for (int j = 0; j < k.ntaps; ++j)
+      for (int s = 0; s < 24; s += 8) {
+        const int d = (int)(int8_t)((k.taps[j] >> s) & 0xff);
+        if (d < 0 || d > 1) return false;
+      }
+  }
+  return taps == 27;
+}
+
+int conv_up_tiles(const ConvKArgs& a) { return ((a.Xr + 3) / 4) * ((a.Yr + 7) / 8) * ((a.Zr + 7) / 8); }
+
+void launch_conv_up(ConvKArgs& a, hipStream_t st) {
+  const int tyn = (a.Yr + 7) / 8, tzn = (a.Zr + 7) / 8;
+  a.tiles = conv_up_tiles(a);
+  const int total = a.tiles * a.N;
+  const int vb = a.Cg * 2;
+  int gx = (vb == 128) ? 256 : 512;
+  if (gx > total) gx = total;
+  if (vb == 128) hipLaunchKernelGGL((conv_up_halo_kernel<128>), dim3(gx), dim3(256), 0, st, a, total, tyn, tzn);
+  else hipLaunchKernelGGL((conv_up_halo_kernel<64>), dim3(gx), dim3(256), 0, st, a, total, tyn, tzn);
+}
+
+}  // namespace ctseg

@@ -76,6 +76,29 @@ def test_halo_kernel_layers_vs_torch_cpu(cin, cout, shape, dt, tol):
     assert rel_err(gb, mod.bias.grad) < tol, "bias gradient"
 
 
+@pytest.mark.parametrize("kind,cin,cout,shape", [("convT", 64, 10, (1, 8, 8, 8)), ("convT", 32, 8, (2, 5, 9, 12)),
+                                                 ("convT", 64, 16, (1, 4, 8, 4)), ("conv_s2", 8, 32, (1, 10, 16, 8)),
+                                                 ("conv_s2", 16, 64, (2, 8, 8, 16))])
+def test_up_halo_kernel_vs_torch_cpu(kind, cin, cout, shape):
+    """8-class stride-2 passes that take conv_up_halo (bf16, gathered channels*2 in {64,128} bytes, <= 16 columns):
+    ConvTranspose3d forward, and the input gradient of a stride-2 Conv3d; ragged tiles included."""
+    torch.manual_seed(cin + cout)
+    if kind == "convT":
+        mod = torch.nn.ConvTranspose3d(cin, cout, 3, 2, 1, output_padding=1)
+    else:
+        mod = torch.nn.Conv3d(cin, cout, 3, 2, 1)
+    x = torch.randn(shape[0], cin, *shape[1:])
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yy, gx, gw, gb = run_conv_module(mod, x, gy, BF16, DEV)
+    assert rel_err(yy, y.detach()) < 2.5e-2, "forward"
+    assert rel_err(gx, xr.grad) < 2.5e-2, "input gradient"
+    assert rel_err(gw, mod.weight.grad) < 2.5e-2, "weight gradient"
+    assert rel_err(gb, mod.bias.grad) < 2.5e-2, "bias gradient"
+
+
 @pytest.mark.parametrize("dt,tol", [(F32, 1e-5), (BF16, 2e-2)])
 def test_instnorm_prelu_fwd_bwd(golden, dt, tol):
     """conv-epilogue statistics -> finalize -> apply, and the 3-kernel backward, against InstanceNorm3d+PReLU."""
