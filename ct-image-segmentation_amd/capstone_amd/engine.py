@@ -365,7 +365,7 @@ class GemmLayer:
 class NormStats:
     def __init__(self, plan, N, tiles, C, count):
         self.plan, self.N, self.tiles, self.C, self.count = plan, N, tiles, C, count
-        self.ld = rup(C, nat.lib().ctseg_conv_tile_cols(C))
+        self.ld = rup(C, 256 if C > 128 else nat.lib().ctseg_conv_tile_cols(C))   # 192x256 tile for C > 128
         self.partials = torch.zeros((N, tiles, 2, self.ld), dtype=torch.float32, device=plan.device)
         self.scratch = torch.zeros((N, 64, 2, self.ld), dtype=torch.float64, device=plan.device)
 
@@ -395,7 +395,7 @@ class Packer:
         zero = self.plan.store.zero_index
         classes = layer.fwd_classes if mode == "fwd" else layer.dg_classes
         rows, gs = layer.rows_gather(mode)
-        rows_pad = rup(rows, 128)
+        rows_pad = rup(rows, 256 if rows > 128 else 128)   # a column tile never reads past the padded rows
         info = {"kpads": [], "w_offs": [], "base": self.total}
         for _, taps in classes:
             nt = len(taps)

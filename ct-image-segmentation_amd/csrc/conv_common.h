@@ -39,7 +39,7 @@ template <typename T, int BM, int BN, int WGM, int WGN>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_conv_class& K, char* smem, float* sStats,
                                               const int* sRow, f32x4 (&acc)[BN / WGN / 16][BM / WGM / 16], int n, int tile,
                                               int cls_index, int col0) {
-  constexpr int SZ = TT<T>::SZ;
+  constexpr int SZ = TT<T>::SZ, NTHR = 64 * WGM * WGN;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, MT = WTM / 16, NT = WTN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -110,14 +110,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
     // latency overlaps (one exposed round trip per batch instead of one per chunk)
     constexpr int UN = 4;
     const int nadd = (af32 || SZ == 4) ? EPO * 4 : EPO * 2;   // addend bytes per chunk: 8, 16 or 32
-    for (int base = tid; base < BM * cpr; base += 256 * UN) {
+    for (int base = tid; base < BM * cpr; base += NTHR * UN) {
       char* op[UN];
       const char* cp[UN];
       u32x4 a0[UN], a1[UN];
       bool ok[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
-        const int idx = base + u * 256;
+        const int idx = base + u * NTHR;
         const int r = (idx < BM * cpr) ? idx / cpr : 0, cc = idx - r * cpr;
         const int ch = col0 + cc * EPO;
         const int z = sRow[2 * r + 1];

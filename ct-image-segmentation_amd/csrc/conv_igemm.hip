@@ -16,25 +16,27 @@
 
 namespace ctseg {
 
-template <int BM, int BN> struct ConvSmem {
+// CSZ = largest output element the epilogue may have to stage (4 unless the configuration never writes fp32)
+template <int BM, int BN, int CSZ = 4> struct ConvSmem {
   static constexpr int BKB = 128;
   static constexpr int STAGE = (BM + BN) * BKB;
-  static constexpr int CROW = BN * 4 + 16;  // epilogue row pitch (sized for fp32 output)
+  static constexpr int CROW = BN * CSZ + 16;  // epilogue row pitch
   static constexpr int MAIN = (2 * STAGE > BM * CROW) ? 2 * STAGE : BM * CROW;
   static constexpr int STATS = 4 * 2 * BN * 4;
   static constexpr int ROWTAB = BM * 8;
-  static constexpr int TOTAL = MAIN + STATS + ROWTAB + 32 * 4;
+  static constexpr int TOTAL = MAIN + STATS + ROWTAB + 64 * 4;
 };
 
 template <typename T, int BM, int BN, int WGM, int WGN, bool SMALLC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs P) {
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvKArgs P) {
+  constexpr int NTHR = 64 * WGM * WGN;     // 4 waves, or 8 for the 192x256 bf16 tile (never fp32 output: CSZ = 2)
   constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
-  constexpr int BKB = 128, BK = BKB / SZ, CH = BKB / 16, RPR = 256 / CH;
+  constexpr int BKB = 128, BK = BKB / SZ, CH = BKB / 16, RPR = NTHR / CH;
   constexpr int AR = BM / RPR;
   constexpr int BR = (BN + RPR - 1) / RPR;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, MT = WTM / 16, NT = WTN / 16;
-  using SM = ConvSmem<BM, BN>;
-  static_assert(WGM * WGN == 4 && MT >= 1 && NT >= 1, "4 waves per workgroup");
+  using SM = ConvSmem<BM, BN, (NTHR == 512 ? TT<T>::SZ : 4)>;
+  static_assert((WGM * WGN == 4 || WGM * WGN == 8) && MT >= 1 && NT >= 1 && BM % RPR == 0, "4 or 8 waves per workgroup");
 
   __shared__ __attribute__((aligned(16))) char smem[SM::TOTAL];
   char* const sA0 = smem;                    // [2][BM][128] then [2][BN][128]
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs P) {
   const int ntaps = K.ntaps, kpad = K.kpad;
 
   // ---- per-tile row table: gathered base coordinates of each GEMM row -------------------------
-  for (int r = tid; r < BM; r += 256) {
+  for (int r = tid; r < BM; r += NTHR) {
     int ri = tile * BM + r;
     int xy = 0, z = -(1 << 24);
     if (ri < P.rows) {
@@ -64,7 +66,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs P) {
     sRow[2 * r] = xy;
     sRow[2 * r + 1] = z;
   }
-  if (tid < 32) sTap[tid] = (tid < ntaps) ? K.taps[tid] : 0;
+  if (tid < 32) {
+    const int tp = (tid < ntaps) ? K.taps[tid] : 0;
+    sTap[tid] = tp;
+    // byte delta of the tap inside the gathered tensor (offsets are in [-1,1] per axis, checked on the host)
+    sTap[32 + tid] = (((int)(int8_t)(tp & 0xff) * P.Yi + (int)(int8_t)((tp >> 8) & 0xff)) * P.Zi + (int)(int8_t)((tp >> 16) & 0xff)) *
+                     P.g_ld * SZ;
+  }
   __syncthreads();
 
   const int q8 = tid % CH, r0 = tid / CH;
@@ -78,23 +86,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs P) {
   // K position of this thread's 16-byte chunk: slot (tap) and channel, advanced stage by stage
   int slot = (q8 * EPC) / P.Cg, ci = (q8 * EPC) % P.Cg;
   const int64_t nbase = (int64_t)n * P.Xi;
+  // per-row constants: byte offset of the row's base voxel, and which of the offsets -1/0/+1 stay inside the tensor
+  // per axis (bits 0-2 x, 3-5 y, 6-8 z; 0 for rows past the end) -> a tap is two shifts and an AND per row per stage
+  int64_t rowb[AR];
+  int rmask[AR], soffA[AR], soffB[BR];
+#pragma unroll
+  for (int j = 0; j < AR; ++j) {
+    const int xb = rxy[j] & 0xffff, yb = rxy[j] >> 16, zb = rz[j];
+    rowb[j] = (((nbase + xb) * P.Yi + yb) * P.Zi + (zb < 0 ? 0 : zb)) * P.g_ld * SZ;
+    int m = 0;
+    if (zb >= 0) {
+#pragma unroll
+      for (int d = -1; d <= 1; ++d) {
+        m |= ((unsigned)(xb + d) < (unsigned)P.Xi) << (d + 1);
+        m |= ((unsigned)(yb + d) < (unsigned)P.Yi) << (d + 4);
+        m |= ((unsigned)(zb + d) < (unsigned)P.Zi) << (d + 7);
+      }
+    }
+    rmask[j] = m;
+    const int r = r0 + j * RPR;
+    soffA[j] = r * BKB + ((q8 ^ ((r >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    const int r = r0 + j * RPR;
+    soffB[j] = r * BKB + ((q8 ^ ((r >> 1) & 7)) << 4);
+  }
   const char* wrow = P.w + (K.w_off + (int64_t)(col0 + r0) * kpad + q8 * EPC) * SZ;
 
-  u32x4 ra[AR], rb[BR];
-  auto gload = [&](int s) {
+  u32x4 ra0[AR], rb0[BR];
+  auto gload = [&](int s, u32x4 (&ra)[AR], u32x4 (&rb)[BR]) {
     if constexpr (!SMALLC) {
-      int tp = (slot < ntaps) ? sTap[slot & 31] : 0;
       const bool sv = slot < ntaps;
-      const int dx = (int)(int8_t)(tp & 0xff), dy = (int)(int8_t)((tp >> 8) & 0xff), dz = (int)(int8_t)((tp >> 16) & 0xff);
+      const int tp = sv ? sTap[slot & 31] : 0;
+      const int tb = (sv ? sTap[32 + (slot & 31)] : 0) + ci * SZ;
+      const int sx = (int)(int8_t)(tp & 0xff) + 1, sy = (int)(int8_t)((tp >> 8) & 0xff) + 4, sz = (int)(int8_t)((tp >> 16) & 0xff) + 7;
 #pragma unroll
       for (int j = 0; j < AR; ++j) {
-        int xi = (rxy[j] & 0xffff) + dx, yi = (rxy[j] >> 16) + dy, zi = rz[j] + dz;
-        bool ok = sv && (unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi;
+        const bool ok = sv && (((rmask[j] >> sx) & (rmask[j] >> sy) & (rmask[j] >> sz) & 1) != 0);
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (ok) {
-          int64_t vox = ((nbase + xi) * P.Yi + yi) * P.Zi + zi;
-          v = *reinterpret_cast<const u32x4*>(P.in + (vox * P.g_ld + ci) * SZ);
-        }
+        if (ok) v = *reinterpret_cast<const u32x4*>(P.in + rowb[j] + tb);
         ra[j] = v;
       }
       ci += BK;
@@ -139,19 +170,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs P) {
       rb[j] = v;
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const u32x4 (&ra)[AR], const u32x4 (&rb)[BR]) {
     char* a = sA0 + buf * BM * BKB;
     char* b = sB0 + buf * BN * BKB;
 #pragma unroll
-    for (int j = 0; j < AR; ++j) {
-      int r = r0 + j * RPR;
-      *reinterpret_cast<u32x4*>(a + r * BKB + ((q8 ^ ((r >> 1) & 7)) << 4)) = ra[j];
-    }
+    for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4*>(a + soffA[j]) = ra[j];
 #pragma unroll
-    for (int j = 0; j < BR; ++j) {
-      int r = r0 + j * RPR;
-      if (BN >= RPR || r < BN) *reinterpret_cast<u32x4*>(b + r * BKB + ((q8 ^ ((r >> 1) & 7)) << 4)) = rb[j];
-    }
+    for (int j = 0; j < BR; ++j)
+      if (BN >= RPR || r0 + j * RPR < BN) *reinterpret_cast<u32x4*>(b + soffB[j]) = rb[j];
   };
 
   f32x4 acc[NT][MT];
@@ -161,13 +187,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs P) {
     for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nst = kpad / BK;
-  gload(0);
-  sstore(0);
-  __syncthreads();
   const int swz = (r16 >> 1) & 7;
-  for (int s = 0; s < nst; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nst) gload(s + 1);
+  auto compute = [&](int buf) {
     const char* a = sA0 + buf * BM * BKB + (wm * WTM + r16) * BKB;
     const char* b = sB0 + buf * BN * BKB + (wn * WTN + r16) * BKB;
 #pragma unroll
@@ -183,7 +204,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs P) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) mma16<T>(acc[j][i], wf[j], xf[i]);
     }
-    if (s + 1 < nst) sstore(buf ^ 1);
+  };
+  // one stage of register prefetch: loads of stage s+1 are in flight while stage s computes.  (A second register set,
+  // two stages ahead, measured SLOWER on MI355X: 0.295 -> 0.362 ms on the 256->256 bottleneck layer.)
+  gload(0, ra0, rb0);
+  sstore(0, ra0, rb0);
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nst) gload(s + 1, ra0, rb0);
+    compute(buf);
+    if (s + 1 < nst) sstore(buf ^ 1, ra0, rb0);
     __syncthreads();
   }
 
@@ -193,14 +224,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs P) {
 template <typename T, int BM, int BN, int WGM, int WGN>
 static int launch_cfg(const ConvKArgs& a, bool smallc, int nclass, hipStream_t st) {
   dim3 grid((unsigned)(a.tiles * a.N), (unsigned)((a.Cn + BN - 1) / BN), (unsigned)nclass);
-  if (smallc) hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, false>), grid, dim3(256), 0, st, a);
+  if (smallc) hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, true>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, false>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return 0;
 }
 
+// rows of the row grid one workgroup tile covers.  Cn > 128 in bf16 (never fp32 output there): 192 x 256 tile, 8 waves —
+// the 128 x 128 tile is bound by the L2 -> LDS operand traffic per CU (64 FLOP/B); 192 x 256 moves 110 FLOP/B, and the
+// M of every layer of the reference's volumes (48 / 24 / 12 / 6 deep) is a multiple of 192.
+static int tile_rows_for(int Cn, int dtype, int out_f32, bool smallc) {
+  if (Cn > 128 && dtype == CTSEG_BF16 && !out_f32 && !smallc) return 192;
+  return Cn <= 32 ? 256 : 128;
+}
+
 template <typename T> static int launch_dtype(ConvKArgs& a, bool smallc, int nclass, hipStream_t st) {
-  const int bm = ctseg_conv_tile_rows(a.Cn);
+  const int bm = tile_rows_for(a.Cn, TT<T>::DT, a.out_f32, smallc);
   a.tiles = (a.rows + bm - 1) / bm;
+  if constexpr (TT<T>::DT == CTSEG_BF16) {
+    if (bm == 192) return launch_cfg<T, 192, 256, 2, 4>(a, false, nclass, st);
+  }
   if (a.Cn <= 16) return launch_cfg<T, 256, 16, 4, 1>(a, smallc, nclass, st);
   if (a.Cn <= 32) return launch_cfg<T, 256, 32, 4, 1>(a, smallc, nclass, st);
   if (a.Cn <= 64) return launch_cfg<T, 128, 64, 2, 2>(a, smallc, nclass, st);
@@ -241,6 +283,11 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
     CTSEG_REQUIRE(k.ntaps >= 1 && k.ntaps <= CTSEG_MAX_TAPS, "conv_igemm: class %d ntaps %d", c, k.ntaps);
     CTSEG_REQUIRE(k.kpad % BK == 0 && k.kpad >= k.ntaps * d->Cg, "conv_igemm: class %d kpad %d", c, k.kpad);
     CTSEG_REQUIRE(((k.w_off * SZ) % 16) == 0, "conv_igemm: class %d weight offset unaligned", c);
+    for (int j = 0; j < k.ntaps; ++j)
+      for (int sh = 0; sh < 24; sh += 8) {
+        const int dd = (int)(int8_t)((k.taps[j] >> sh) & 0xff);
+        CTSEG_REQUIRE(dd >= -1 && dd <= 1, "conv_igemm: class %d tap %d offset %d outside [-1,1]", c, j, dd);
+      }
     CTSEG_REQUIRE(k.ox >= 0 && k.oy >= 0 && k.oz >= 0 && k.ox < d->sout && k.oy < d->sout && k.oz < d->sout,
                   "conv_igemm: class %d output parity", c);
   }
@@ -262,9 +309,9 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   if (d->stats && up) {
     CTSEG_REQUIRE(d->stats_tile0 + conv_up_tiles(a) <= d->stats_tiles && d->stats_ld >= 16, "conv_igemm: stats partial layout (up pass)");
   } else if (d->stats) {
-    const int bm = ctseg_conv_tile_rows(d->Cn);
+    const int bm = tile_rows_for(d->Cn, d->dtype, d->out_f32, smallc);
     const int tiles = halo ? conv_halo_tiles(a) : (a.rows + bm - 1) / bm;
-    const int bn = ctseg_conv_tile_cols(d->Cn);
+    const int bn = bm == 192 ? 256 : ctseg_conv_tile_cols(d->Cn);
     CTSEG_REQUIRE(d->stats_tile0 + tiles * d->nclass <= d->stats_tiles && d->stats_ld >= ((d->Cn + bn - 1) / bn) * bn,
                   "conv_igemm: stats partial layout (need stats_ld >= roundup(Cn, tile cols))");
   }
@@ -291,6 +338,8 @@ extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
   if (conv_halo_eligible(a, d->dtype, d->nclass)) return conv_halo_tiles(a);
   a.out_f32 = d->out_f32; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo;
   if (conv_up_eligible(a, d->dtype, d->nclass)) return conv_up_tiles(a);
-  const int bm = ctseg_conv_tile_rows(d->Cn);
+  const int SZq = d->dtype == CTSEG_F32 ? 4 : 2, EPCq = 16 / SZq;
+  const bool smallq = (d->Cg % EPCq) != 0 || (d->g_ld % EPCq) != 0 || ((uintptr_t)d->in % 16) != 0;
+  const int bm = tile_rows_for(d->Cn, d->dtype, d->out_f32, smallq);
   return ((a.rows + bm - 1) / bm) * d->nclass;
 }
