@@ -205,17 +205,38 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvKA
         for (int i = 0; i < MT; ++i) mma16<T>(acc[j][i], wf[j], xf[i]);
     }
   };
-  // one stage of register prefetch: loads of stage s+1 are in flight while stage s computes.  (A second register set,
-  // two stages ahead, measured SLOWER on MI355X: 0.295 -> 0.362 ms on the 256->256 bottleneck layer.)
-  gload(0, ra0, rb0);
-  sstore(0, ra0, rb0);
-  __syncthreads();
-  for (int s = 0; s < nst; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nst) gload(s + 1, ra0, rb0);
-    compute(buf);
-    if (s + 1 < nst) sstore(buf ^ 1, ra0, rb0);
+  if constexpr (NTHR == 512) {
+    // 8-wave tile, ONE workgroup per CU: nothing else hides the load latency, so keep two stages in flight (two
+    // register sets; stage s+2 is requested while stage s computes)
+    u32x4 ra1[AR], rb1[BR];
+    gload(0, ra0, rb0);
+    sstore(0, ra0, rb0);
+    if (nst > 1) gload(1, ra1, rb1);
     __syncthreads();
+    for (int s = 0; s < nst; s += 2) {
+      if (s + 2 < nst) gload(s + 2, ra0, rb0);
+      compute(0);
+      if (s + 1 < nst) sstore(1, ra1, rb1);
+      __syncthreads();
+      if (s + 1 >= nst) break;
+      if (s + 3 < nst) gload(s + 3, ra1, rb1);
+      compute(1);
+      if (s + 2 < nst) sstore(0, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    // 4-wave tiles run 2+ workgroups per CU; there a second register set measured SLOWER (0.295 -> 0.362 ms on the
+    // 256->256 layer with the 128x128 tile): one stage of register prefetch
+    gload(0, ra0, rb0);
+    sstore(0, ra0, rb0);
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nst) gload(s + 1, ra0, rb0);
+      compute(buf);
+      if (s + 1 < nst) sstore(buf ^ 1, ra0, rb0);
+      __syncthreads();
+    }
   }
 
   conv_epilogue<T, BM, BN, WGM, WGN>(P, K, smem, sStats, sRow, acc, n, tile, (int)blockIdx.z, col0);
