@@ -283,7 +283,7 @@ class Plan:
 
     def emit_colsum(self, x, out_ptr):
         rows = x.dims[0] * x.S
-        P = max(1, min(256, math.ceil(rows / 4096)))
+        P = max(1, min(2048, math.ceil(rows / 2048)))
         part = torch.zeros((P, rup(x.C, 8)), dtype=torch.float32, device=self.device)
         self.emit("ctseg_colsum", self.dt, x.ptr(), x.ld, rows, x.C, part.data_ptr(), P, out_ptr, keep=(x, part))
 

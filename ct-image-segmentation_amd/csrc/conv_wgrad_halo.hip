@@ -41,6 +41,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
   const int r16 = lane & 15, q4 = lane >> 4;
   const int tq = r16 >> 2, tp = r16 & 3;
 
+  // per-thread constants of the staging slots (only a scalar tile base changes from tile to tile)
+  const int YZ = P.Y * P.Z;
+  int gx_byte[JX], gx_hxyz[JX], gx_lds[JX], gd_byte[JD], gd_xyz[JD], gd_lds[JD];
+#pragma unroll
+  for (int j = 0; j < JX; ++j) {
+    const int idx = tid + j * 256;
+    const int c = idx % (VB / 16), hv = idx / (VB / 16);
+    const int hx = hv / 100, rem = hv - hx * 100, hy = rem / 10, hz = rem - hy * 10;
+    gx_byte[j] = (((hx - 1) * YZ + (hy - 1) * P.Z + (hz - 1)) * P.g_ld + c * 8) * 2;
+    gx_hxyz[j] = (idx < XCH) ? (hx | (hy << 8) | (hz << 16)) : 0x7f7f7f;
+    gx_lds[j] = (c >> 1) * (WH_HV * 32) + hv * 32 + (c & 1) * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < JD; ++j) {
+    const int idx = tid + j * 256;
+    const int c = idx % (DBY / 16), tv = idx / (DBY / 16);
+    const int tx = tv >> 6, ty = (tv >> 3) & 7, tz = tv & 7;
+    gd_byte[j] = ((tx * YZ + ty * P.Z + tz) * P.d_ld + c * 8) * 2;
+    gd_xyz[j] = (idx < DCH) ? (tx | (ty << 8) | (tz << 16)) : 0x7f7f7f;
+    gd_lds[j] = (c >> 1) * (WH_TV * 32) + tv * 32 + (c & 1) * 16;
+  }
   u32x4 rx[JX], rd[JD];
   auto origin = [&](int t, int& n, int& x0, int& y0, int& z0) {
     n = t / P.tiles;
@@ -52,33 +73,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
   auto gload = [&](int t) {
     int n, x0, y0, z0;
     origin(t, n, x0, y0, z0);
+    const int64_t vb = (((int64_t)n * P.X + x0) * P.Y + y0) * P.Z + z0;
+    const char* xb = P.in + vb * P.g_ld * 2;
+    const char* db = P.dy + vb * P.d_ld * 2;
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
-      const int idx = tid + j * 256;
+      const int xi = x0 - 1 + (gx_hxyz[j] & 0xff), yi = y0 - 1 + ((gx_hxyz[j] >> 8) & 0xff), zi = z0 - 1 + (gx_hxyz[j] >> 16);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx < XCH) {
-        const int c = idx % (VB / 16), hv = idx / (VB / 16);
-        const int hx = hv / 100, rem = hv - hx * 100, hy = rem / 10, hz = rem - hy * 10;
-        const int xi = x0 - 1 + hx, yi = y0 - 1 + hy, zi = z0 - 1 + hz;
-        if ((unsigned)xi < (unsigned)P.X && (unsigned)yi < (unsigned)P.Y && (unsigned)zi < (unsigned)P.Z) {
-          const int64_t vox = (((int64_t)n * P.X + xi) * P.Y + yi) * P.Z + zi;
-          v = *reinterpret_cast<const u32x4*>(P.in + (vox * P.g_ld + c * 8) * 2);
-        }
-      }
+      if ((unsigned)xi < (unsigned)P.X && (unsigned)yi < (unsigned)P.Y && (unsigned)zi < (unsigned)P.Z)
+        v = *reinterpret_cast<const u32x4*>(xb + gx_byte[j]);
       rx[j] = v;
     }
 #pragma unroll
     for (int j = 0; j < JD; ++j) {
-      const int idx = tid + j * 256;
+      const int xi = x0 + (gd_xyz[j] & 0xff), yi = y0 + ((gd_xyz[j] >> 8) & 0xff), zi = z0 + (gd_xyz[j] >> 16);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx < DCH) {
-        const int c = idx % (DBY / 16), tv = idx / (DBY / 16);
-        const int xi = x0 + (tv >> 6), yi = y0 + ((tv >> 3) & 7), zi = z0 + (tv & 7);
-        if (xi < P.X && yi < P.Y && zi < P.Z) {
-          const int64_t vox = (((int64_t)n * P.X + xi) * P.Y + yi) * P.Z + zi;
-          v = *reinterpret_cast<const u32x4*>(P.dy + (vox * P.d_ld + c * 8) * 2);
-        }
-      }
+      if (xi < P.X && yi < P.Y && zi < P.Z) v = *reinterpret_cast<const u32x4*>(db + gd_byte[j]);
       rd[j] = v;
     }
   };
@@ -86,21 +96,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
     char* xs = smem + buf * BUF;
     char* ds = xs + XBYTES;
 #pragma unroll
-    for (int j = 0; j < JX; ++j) {
-      const int idx = tid + j * 256;
-      if (idx < XCH) {
-        const int c = idx % (VB / 16), hv = idx / (VB / 16);
-        *reinterpret_cast<u32x4*>(xs + (c >> 1) * (WH_HV * 32) + hv * 32 + (c & 1) * 16) = rx[j];
-      }
-    }
+    for (int j = 0; j < JX; ++j)
+      if (JX * 256 == XCH || tid + j * 256 < XCH) *reinterpret_cast<u32x4*>(xs + gx_lds[j]) = rx[j];
 #pragma unroll
-    for (int j = 0; j < JD; ++j) {
-      const int idx = tid + j * 256;
-      if (idx < DCH) {
-        const int c = idx % (DBY / 16), tv = idx / (DBY / 16);
-        *reinterpret_cast<u32x4*>(ds + (c >> 1) * (WH_TV * 32) + tv * 32 + (c & 1) * 16) = rd[j];
-      }
-    }
+    for (int j = 0; j < JD; ++j)
+      if (JD * 256 == DCH || tid + j * 256 < DCH) *reinterpret_cast<u32x4*>(ds + gd_lds[j]) = rd[j];
   };
 
   f32x4 acc[7][PA][PB];
@@ -144,9 +144,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
         df[b] = __builtin_bit_cast(bf16x8, v);
       }
       const int hbase = (((x + 1) * 10) + (yb + ly + 1)) * 10 + (lz + 1);
+      // taps wave, wave+4, ..., wave+20 always exist: fetch all their operands first, then issue the MFMAs back to back
+      // (branch-free, so the LDS latency of one tap hides behind the others); tap wave+24 may be the pseudo tap 27
+      bf16x8 af[6][PA];
 #pragma unroll
-      for (int ti = 0; ti < 7; ++ti) {
-        const int tap = wave + 4 * ti;
+      for (int ti = 0; ti < 6; ++ti) {
+        const int h = hbase + P.delta[wave + 4 * ti];
+#pragma unroll
+        for (int a = 0; a < PA; ++a) {
+          const char* p0 = xs + a * (WH_HV * 32) + h * 32 + tp * 8;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 2 * 10 * 32));
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          af[ti][a] = __builtin_bit_cast(bf16x8, v);
+        }
+      }
+#pragma unroll
+      for (int ti = 0; ti < 6; ++ti)
+#pragma unroll
+        for (int a = 0; a < PA; ++a)
+#pragma unroll
+          for (int b = 0; b < PB; ++b)
+            acc[ti][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ti][a], df[b], acc[ti][a][b], 0, 0, 0);
+      {
+        const int tap = wave + 24;
         if (tap < 27) {
           const int h = hbase + P.delta[tap];
 #pragma unroll
@@ -155,14 +176,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 2 * 10 * 32));
             const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const bf16x8 af = __builtin_bit_cast(bf16x8, v);
+            const bf16x8 a6 = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
-            for (int b = 0; b < PB; ++b) acc[ti][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, df[b], acc[ti][a][b], 0, 0, 0);
+            for (int b = 0; b < PB; ++b) acc[6][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a6, df[b], acc[6][a][b], 0, 0, 0);
           }
         } else {  // pseudo tap 27: x == 1 on channel row 0 -> row 0 of the tile accumulates sum(dy) (bias gradient)
 #pragma unroll
           for (int b = 0; b < PB; ++b)
-            acc[ti][0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), df[b], acc[ti][0][b], 0, 0, 0);
+            acc[6][0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), df[b], acc[6][0][b], 0, 0, 0);
         }
       }
     }
@@ -198,6 +219,7 @@ bool wgrad_halo_eligible(const ctseg_wgrad_desc* d) {
   if (d->Xr != d->Xi || d->Yr != d->Yi || d->Zr != d->Zi || d->Zr < 4) return false;
   if (d->g_ld % 8 || d->d_ld % 8 || d->d_ld < db / 2 || ((uintptr_t)d->in % 16) || ((uintptr_t)d->dy % 16)) return false;
   if (d->cn_pad < db / 2) return false;
+  if ((int64_t)d->Xi * d->Yi * d->Zi * (d->g_ld > d->d_ld ? d->g_ld : d->d_ld) * 2 >= (1ll << 31)) return false;  // 32-bit per-sample byte offsets
   for (int j = 0; j < 27; ++j)
     for (int s = 0; s < 24; s += 8) {
       const int v = (int)(int8_t)((d->taps[j] >> s) & 0xff);

@@ -254,11 +254,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const char* __restr
     partials[(int64_t)p * pld + c] = s;
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partials, int P, int pld, int C, float* __restrict__ out) {
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double s = 0.0;
-    for (int p = 0; p < P; ++p) s += (double)partials[(int64_t)p * pld + c];
-    out[c] = (float)s;
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partials, int P, int pld, int C,
+                                                             float* __restrict__ out) {
+  // thread = (sub, c): 1024 / pld strided sub-sums over the P partial rows, combined in fixed order
+  __shared__ double s_acc[1024];
+  const int lanes = pld, subs = 1024 / lanes;
+  const int c = (int)threadIdx.x % lanes, sub = (int)threadIdx.x / lanes;
+  double s = 0.0;
+  if (sub < subs && c < C)
+    for (int p = sub; p < P; p += subs) s += (double)partials[(int64_t)p * pld + c];
+  s_acc[threadIdx.x] = s;
+  __syncthreads();
+  if (sub == 0 && c < C) {
+    double t = 0.0;
+    for (int k = 0; k < subs; ++k) t += s_acc[k * lanes + c];
+    out[c] = (float)t;
   }
 }
 
@@ -367,7 +377,7 @@ extern "C" int ctseg_colsum(int32_t dtype, const void* x, int32_t ld, int64_t ro
     hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(P), dim3(256), 0, st, (const char*)x, ld, rows, C, Cv, partials, P, pld);
   else
     hipLaunchKernelGGL(colsum_partial_kernel<BF16>, dim3(P), dim3(256), 0, st, (const char*)x, ld, rows, C, Cv, partials, P, pld);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, st, partials, P, pld, C, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(1024), 0, st, partials, P, pld, C, out);
   CTSEG_LAUNCH_CHECK("colsum");
   return 0;
 }
