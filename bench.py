@@ -169,8 +169,12 @@ def main():
             flop = 2.0 * n_ * x_ * y_ * z_ * 256 * 256 * 27
             peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
             ach = flop / (kms * 1e-3) / 1e12
+            traffic = None     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this very kernel
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_bottleneck.json")
+            if args.precision == "bf16" and (B, H, W, D) == (2, 512, 512, 48) and os.path.exists(pmc):
+                traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                               "traffic": None, "kernel": "conv_igemm_kernel<BF16,128,128> encoder-bottleneck Conv3d 256->256 k3",
+                               "traffic": traffic, "kernel": "conv_igemm_kernel<BF16,192,256> encoder-bottleneck Conv3d 256->256 k3",
                                "launch_ms": kms, "flop_per_launch": flop}
         if world == 1 and not args.no_cpu_baseline:
             try:
