@@ -24,8 +24,11 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
-    if backend == "nccl":
+        # "nccl" is RCCL on ROCm.  CTSEG_DIST_BACKEND=gloo + CTSEG_SINGLE_DEVICE=1 rehearse the N>1 path on a one-GPU box
+        backend = os.environ.get("CTSEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if os.environ.get("CTSEG_SINGLE_DEVICE") == "1":
+        local = 0
+    if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
