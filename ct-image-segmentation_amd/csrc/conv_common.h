@@ -165,6 +165,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
 // LDS-halo kernel (conv_halo.hip): 3x3x3 stride-1 passes with few channels, input tile staged once for all 27 taps
 bool conv_halo_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_halo_tiles(const ConvKArgs& a);
+int conv_halo_slots(const ConvKArgs& a, int dtype);   // InstanceNorm partial slots per sample (= workgroups)
 void launch_conv_halo(ConvKArgs& a, int dtype, hipStream_t st);
 // 8-class stride-2 "up" pass with <= 16 output channels (conv_up_halo.hip): one input tile for all parity classes
 bool conv_up_eligible(const ConvKArgs& a, int dtype, int nclass);

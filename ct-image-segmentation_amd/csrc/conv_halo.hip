@@ -40,7 +40,7 @@ template <int VB, int NT> struct HaloCfg {
   static constexpr int TOTAL = WBYTES + 2 * HALO + 4 * 2 * BN * 4 + 32 * 4;
 };
 
-template <typename T, int VB, int NT>
+template <typename T, int VB, int NT, bool STATS>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int total_tiles, int tyn, int tzn) {
   constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
   using CF = HaloCfg<VB, NT>;
@@ -138,9 +138,47 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
       bias[j][e] = (P.bias != nullptr && ch < P.Cn) ? P.bias[ch] : 0.f;
     }
 
+  // InstanceNorm partial sums are kept in registers across the workgroup's tiles and written once per (workgroup, sample):
+  // one partial slot per workgroup instead of one per tile (no per-tile barrier, 30x fewer partials to finalize)
+  float wsum[NT][4], wsq[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { wsum[j][e] = 0.f; wsq[j][e] = 0.f; }
+  int stat_n = -1;
+  auto flush_stats = [&](int n) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = wsum[j][e], b = wsq[j][e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (r16 == 0) {
+          const int c = j * 16 + 4 * q4 + e;
+          sStats[(wave * 2 + 0) * BN + c] = a;
+          sStats[(wave * 2 + 1) * BN + c] = b;
+        }
+        wsum[j][e] = 0.f;
+        wsq[j][e] = 0.f;
+      }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, c = tid % BN;
+      const float a = sStats[(0 * 2 + which) * BN + c] + sStats[(1 * 2 + which) * BN + c] + sStats[(2 * 2 + which) * BN + c] +
+                      sStats[(3 * 2 + which) * BN + c];
+      const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + blockIdx.x;
+      P.stats[(slot_t * 2 + which) * P.stats_ld + col0 + c] = a;
+    }
+    __syncthreads();
+  };
   auto compute_tile = [&](int t, int buf) {
     int n, x0, y0, z0;
     tile_origin(t, n, x0, y0, z0);
+    if (STATS && n != stat_n) {
+      if (stat_n >= 0) flush_stats(stat_n);
+      stat_n = n;
+    }
     f32x4 acc[NT][4];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -190,20 +228,17 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
           av[j][i] = v;
         }
     }
-    float ssum[NT][4], ssq[NT][4];
     char* ob = P.out + vb * P.o_ld * OSZ;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int ch = col0 + j * 16 + 4 * q4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { ssum[j][e] = 0.f; ssq[j][e] = 0.f; }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = acc[j][i][e] + bias[j][e];
-          if (rv[i]) { ssum[j][e] += v[e]; ssq[j][e] += v[e] * v[e]; }
+          if (STATS && rv[i]) { wsum[j][e] += v[e]; wsq[j][e] += v[e] * v[e]; }
         }
         if (P.add != nullptr) {
           if (af32) {
@@ -219,29 +254,6 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
           if (OSZ == 4) *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
           else *reinterpret_cast<u32x2*>(op) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
         }
-      }
-    }
-    if (P.stats != nullptr) {   // per-(tile, channel) partial sums: 16 voxel lanes -> wave -> workgroup, one slot per tile
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float a = ssum[j][e], b = ssq[j][e];
-#pragma unroll
-          for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-          if (r16 == 0) {
-            const int c = j * 16 + 4 * q4 + e;
-            sStats[(wave * 2 + 0) * BN + c] = a;
-            sStats[(wave * 2 + 1) * BN + c] = b;
-          }
-        }
-      __syncthreads();
-      if (tid < 2 * BN) {
-        const int which = tid / BN, c = tid % BN;
-        const float a = sStats[(0 * 2 + which) * BN + c] + sStats[(1 * 2 + which) * BN + c] + sStats[(2 * 2 + which) * BN + c] +
-                        sStats[(3 * 2 + which) * BN + c];
-        const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + (t - n * tiles_per_sample);
-        P.stats[(slot_t * 2 + which) * P.stats_ld + col0 + c] = a;
       }
     }
   };
@@ -281,6 +293,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
     ta = tc;
     tb = td;
   }
+  if (STATS && stat_n >= 0) flush_stats(stat_n);
 }
 
 bool conv_halo_eligible(const ConvKArgs& a, int dtype, int nclass) {
@@ -305,15 +318,27 @@ int conv_halo_tiles(const ConvKArgs& a) {
   return ((a.Xr + H_TX - 1) / H_TX) * ((a.Yr + H_TY - 1) / H_TY) * ((a.Zr + H_TZ - 1) / H_TZ);
 }
 
+template <int VB, int NT> static int halo_grid(int total) {
+  const int per_cu = HaloCfg<VB, NT>::TOTAL > 80 * 1024 ? 1 : (HaloCfg<VB, NT>::TOTAL > 54000 ? 2 : 3);   // 160 KiB LDS per CU
+  const int gx = 256 * per_cu;
+  return gx > total ? total : gx;
+}
+
+// workgroups (= InstanceNorm partial slots per sample) a launch with this geometry uses
+int conv_halo_slots(const ConvKArgs& a, int dtype) {
+  const int vb = a.Cg * (dtype == CTSEG_F32 ? 4 : 2), total = conv_halo_tiles(a) * a.N;
+  if (vb == 64) return a.Cn > 16 ? halo_grid<64, 2>(total) : halo_grid<64, 1>(total);
+  return a.Cn > 16 ? halo_grid<32, 2>(total) : halo_grid<32, 1>(total);
+}
+
 template <typename T, int VB, int NT> static void launch_halo(ConvKArgs& a, hipStream_t st) {
   const int tyn = (a.Yr + H_TY - 1) / H_TY, tzn = (a.Zr + H_TZ - 1) / H_TZ;
   a.tiles = conv_halo_tiles(a);
   const int total = a.tiles * a.N;
-  const int per_cu = HaloCfg<VB, NT>::TOTAL > 80 * 1024 ? 1 : (HaloCfg<VB, NT>::TOTAL > 54000 ? 2 : 3);   // 160 KiB LDS per CU
-  int gx = 256 * per_cu;
-  if (gx > total) gx = total;
+  const int gx = halo_grid<VB, NT>(total);
   dim3 grid((unsigned)gx, (unsigned)((a.Cn + 16 * NT - 1) / (16 * NT)), 1);
-  hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT>), grid, dim3(256), 0, st, a, total, tyn, tzn);
+  if (a.stats != nullptr) hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, true>), grid, dim3(256), 0, st, a, total, tyn, tzn);
+  else hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, false>), grid, dim3(256), 0, st, a, total, tyn, tzn);
 }
 
 void launch_conv_halo(ConvKArgs& a, int dtype, hipStream_t st) {

@@ -331,7 +331,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
     CTSEG_REQUIRE(d->stats_tile0 + conv_up_tiles(a) <= d->stats_tiles && d->stats_ld >= 16, "conv_igemm: stats partial layout (up pass)");
   } else if (d->stats) {
     const int bm = tile_rows_for(d->Cn, d->dtype, d->out_f32, smallc);
-    const int tiles = halo ? conv_halo_tiles(a) : (a.rows + bm - 1) / bm;
+    const int tiles = halo ? conv_halo_slots(a, d->dtype) : (a.rows + bm - 1) / bm;
     const int bn = bm == 192 ? 256 : ctseg_conv_tile_cols(d->Cn);
     CTSEG_REQUIRE(d->stats_tile0 + tiles * d->nclass <= d->stats_tiles && d->stats_ld >= ((d->Cn + bn - 1) / bn) * bn,
                   "conv_igemm: stats partial layout (need stats_ld >= roundup(Cn, tile cols))");
@@ -356,7 +356,7 @@ extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
   if (d == nullptr || d->nclass < 1) return -1;
   ConvKArgs a;
   fill_args(d, a);
-  if (conv_halo_eligible(a, d->dtype, d->nclass)) return conv_halo_tiles(a);
+  if (conv_halo_eligible(a, d->dtype, d->nclass)) return conv_halo_slots(a, d->dtype);
   a.out_f32 = d->out_f32; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo;
   if (conv_up_eligible(a, d->dtype, d->nclass)) return conv_up_tiles(a);
   const int SZq = d->dtype == CTSEG_F32 ? 4 : 2, EPCq = 16 / SZq;
