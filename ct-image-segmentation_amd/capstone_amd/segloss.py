@@ -83,9 +83,10 @@ class SegLossEngine:
 
     # ---- passes ----
     def _pass(self, logits_ptr, ld, cw, do_stats, do_grad, coef=None, dl_ptr=None, g_ld=0, gdt=F32, pred=None, part=None):
+        """do_stats / do_grad: False, True, or 2 = cross-entropy-only fast path of the kernel"""
         nat.call("ctseg_seg_loss", logits_ptr, ld, self.labels.data_ptr(), self.B, self.S, self.C, nat.ptr(cw),
-                 1 if do_stats else 0, nat.ptr(part if part is not None else self.part), self.P, self.cnt.data_ptr(),
-                 1 if do_grad else 0, nat.ptr(coef), dl_ptr, g_ld, gdt, nat.ptr(pred))
+                 int(do_stats), nat.ptr(part if part is not None else self.part), self.P, self.cnt.data_ptr(),
+                 int(do_grad), nat.ptr(coef), dl_ptr, g_ld, gdt, nat.ptr(pred))
 
     def stats(self, logits_ptr, ld, weighted_too=False):
         self.cnt.zero_()
@@ -104,7 +105,7 @@ class SegLossEngine:
         denom = (self.hist.double() * w[None, :]).sum()
         self.coef.zero_()
         self.coef[:, 0] = (1.0 / denom).float()
-        self._pass(logits_ptr, ld, self.cw if weighted else None, True, True, self.coef, dl_ptr, g_ld, gdt)
+        self._pass(logits_ptr, ld, self.cw if weighted else None, 2, 2, self.coef, dl_ptr, g_ld, gdt)
         nat.call("ctseg_reduce_partials_f64", self.part.data_ptr(), self.B, self.P, self.R,
                  (self.red_w if weighted else self.red).data_ptr())
 

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void squash_masks_kernel(const uint8_t* __rest
 }
 
 // One pass over fp32 channels-last logits.  Block (p, b) covers voxels [p*vp, (p+1)*vp) of sample b.
-template <typename GT>
+// SOFT = false: cross-entropy-only fast path (the reference's 3-D default): no soft-Dice / focal sums, CE-only gradient
+template <typename GT, bool SOFT>
 __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__ logits, int ld, const uint8_t* __restrict__ labels,
                                                        int64_t S, int C, const float* __restrict__ class_weight, int do_stats,
                                                        double* __restrict__ part, int P, unsigned long long* __restrict__ cnt,
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
 #pragma unroll
       for (int c = 0; c < CMAX; ++c) {
         if (c < C) {
-          a_p[c] += pr[c];
-          if (c == t) { a_py[c] += pr[c]; a_fo[c] += fo; c_tr[c] += 1u; }
+          if (SOFT) a_p[c] += pr[c];
+          if (c == t) { if (SOFT) { a_py[c] += pr[c]; a_fo[c] += fo; } c_tr[c] += 1u; }
           if (c == pred) { c_pr[c] += 1u; if (c == t) c_in[c] += 1u; }
         }
       }
@@ -151,20 +152,25 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
     if (do_grad) {
       const float ce_scale = s_coef[0] * w;
       // soft-Dice: dL/dp_c = a_c*[c==t] + b_c ; through softmax: p_k (g_k - sum_j g_j p_j)
-      float gk[CMAX], dot = 0.f;
-#pragma unroll
-      for (int c = 0; c < CMAX; ++c) {
-        gk[c] = (c < C) ? (s_coef[1 + CMAX + c] + (c == t ? s_coef[1 + c] : 0.f)) : 0.f;
-        dot += gk[c] * pr[c];
-      }
-      const float ft = s_coef[1 + 2 * CMAX + (t < CMAX ? t : 0)];
-      const float om = 1.f - pt;
-      const float fterm = ft * (2.f * om * pt * logpt - om * om);
       float d[CMAX];
+      if constexpr (SOFT) {
+        float gk[CMAX], dot = 0.f;
 #pragma unroll
-      for (int c = 0; c < CMAX; ++c) {
-        const float ind = (c == t) ? 1.f : 0.f;
-        d[c] = (c < C) ? (ce_scale * (pr[c] - ind) + pr[c] * (gk[c] - dot) + fterm * (ind - pr[c])) : 0.f;
+        for (int c = 0; c < CMAX; ++c) {
+          gk[c] = (c < C) ? (s_coef[1 + CMAX + c] + (c == t ? s_coef[1 + c] : 0.f)) : 0.f;
+          dot += gk[c] * pr[c];
+        }
+        const float ft = s_coef[1 + 2 * CMAX + (t < CMAX ? t : 0)];
+        const float om = 1.f - pt;
+        const float fterm = ft * (2.f * om * pt * logpt - om * om);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+          const float ind = (c == t) ? 1.f : 0.f;
+          d[c] = (c < C) ? (ce_scale * (pr[c] - ind) + pr[c] * (gk[c] - dot) + fterm * (ind - pr[c])) : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) d[c] = (c < C) ? ce_scale * (pr[c] - ((c == t) ? 1.f : 0.f)) : 0.f;
       }
       char* gp = dlogits + vox * g_ld * GSZ;
 #pragma unroll
@@ -181,7 +187,8 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
     for (int c = 0; c < CMAX; ++c) { rec[2 + c] = a_p[c]; rec[2 + CMAX + c] = a_py[c]; rec[2 + 2 * CMAX + c] = a_fo[c]; }
 #pragma unroll
     for (int i = 0; i < 2 + 3 * CMAX; ++i) {
-      const double s = wave_sum(rec[i]);
+      double s = 0.0;
+      if (SOFT || i < 2) s = wave_sum(rec[i]);
       if (lane == 0) s_part[wave][i] = s;
     }
 #pragma unroll
@@ -278,12 +285,14 @@ extern "C" int ctseg_seg_loss(const float* logits, int32_t ld, const uint8_t* la
     CTSEG_REQUIRE(g_ld % gepc == 0 && g_ld >= C && g_ld <= CMAX && ((uintptr_t)dlogits % 16) == 0, "seg_loss: dlogits stride %d", g_ld);
   }
   hipStream_t st = (hipStream_t)stream;
-  if (do_grad && gdtype == CTSEG_BF16)
-    hipLaunchKernelGGL(seg_loss_kernel<BF16>, dim3(P, B), dim3(256), 0, st, logits, ld, labels, S, C, class_weight, do_stats, part,
-                       P, (unsigned long long*)cnt, do_grad, coef, (char*)dlogits, g_ld, pred_out);
-  else
-    hipLaunchKernelGGL(seg_loss_kernel<float>, dim3(P, B), dim3(256), 0, st, logits, ld, labels, S, C, class_weight, do_stats, part,
-                       P, (unsigned long long*)cnt, do_grad, coef, (char*)dlogits, g_ld, pred_out);
+  const bool lite = (do_stats == 2 || do_stats == 0) && (do_grad == 2 || do_grad == 0);   // cross-entropy only
+  const bool gbf = do_grad && gdtype == CTSEG_BF16;
+#define CTSEG_LOSS_LAUNCH(GT, SOFT)                                                                                          \
+  hipLaunchKernelGGL((seg_loss_kernel<GT, SOFT>), dim3(P, B), dim3(256), 0, st, logits, ld, labels, S, C, class_weight, do_stats, \
+                     part, P, (unsigned long long*)cnt, do_grad, coef, (char*)dlogits, g_ld, pred_out)
+  if (gbf) { if (lite) CTSEG_LOSS_LAUNCH(BF16, false); else CTSEG_LOSS_LAUNCH(BF16, true); }
+  else { if (lite) CTSEG_LOSS_LAUNCH(float, false); else CTSEG_LOSS_LAUNCH(float, true); }
+#undef CTSEG_LOSS_LAUNCH
   CTSEG_LAUNCH_CHECK("seg_loss");
   return 0;
 }

@@ -141,6 +141,7 @@ int ctseg_squash_masks(const uint8_t* masks, int32_t B, int32_t K, int64_t S, ui
  * monai DiceLoss / FocalLoss.  do_stats: per-workgroup partials part[B][P][2+3C] doubles
  *   (sum w*nll, sum w, then per class sum p, sum p*y, sum focal) and integer counts cnt[B][3][C]
  *   (|pred==c & true==c|, |pred==c|, |true==c|; int64, zeroed by the caller).
+ * do_stats / do_grad = 2 select the cross-entropy-only fast path (soft sums left 0, gradient = ce term only).
  * do_grad: dlogits = coef-weighted gradient, coef[B][1+3C] fp32 = (ce_scale, a[C], b[C], f[C]):
  *   ce_scale*w[t]*(p-onehot) + softmax-jacobian of (a_c*y_c + b_c) + focal term f_t.  dlogits dtype = gdtype. */
 int ctseg_seg_loss(const float* logits, int32_t ld, const uint8_t* labels, int32_t B, int64_t S, int32_t C,
