@@ -171,5 +171,9 @@ void launch_conv_halo(ConvKArgs& a, int dtype, hipStream_t st);
 bool conv_up_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_up_tiles(const ConvKArgs& a);
 void launch_conv_up(ConvKArgs& a, hipStream_t st);
+// single-channel 3x3x3 stride-2 stem (conv_stem.hip)
+bool conv_stem_eligible(const ConvKArgs& a, int dtype, int nclass);
+int conv_stem_slots(const ConvKArgs& a);
+void launch_conv_stem(ConvKArgs& a, hipStream_t st);
 
 }  // namespace ctseg

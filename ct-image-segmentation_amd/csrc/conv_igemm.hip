@@ -327,7 +327,11 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
   const bool halo = conv_halo_eligible(a, d->dtype, d->nclass);
   const bool up = !halo && conv_up_eligible(a, d->dtype, d->nclass);
-  if (d->stats && up) {
+  const bool stem = !halo && !up && conv_stem_eligible(a, d->dtype, d->nclass);
+  if (d->stats && stem) {
+    CTSEG_REQUIRE(d->stats_tile0 + conv_stem_slots(a) <= d->stats_tiles && d->stats_ld >= ((d->Cn + 15) / 16) * 16,
+                  "conv_igemm: stats partial layout (stem pass)");
+  } else if (d->stats && up) {
     CTSEG_REQUIRE(d->stats_tile0 + conv_up_tiles(a) <= d->stats_tiles && d->stats_ld >= 16, "conv_igemm: stats partial layout (up pass)");
   } else if (d->stats) {
     const int bm = tile_rows_for(d->Cn, d->dtype, d->out_f32, smallc);
@@ -339,6 +343,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (halo) launch_conv_halo(a, d->dtype, st);
   else if (up) launch_conv_up(a, st);
+  else if (stem) launch_conv_stem(a, st);
   else if (d->dtype == CTSEG_F32) launch_dtype<float>(a, smallc, d->nclass, st);
   else launch_dtype<BF16>(a, smallc, d->nclass, st);
   CTSEG_LAUNCH_CHECK("conv_igemm");
@@ -359,6 +364,8 @@ extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
   if (conv_halo_eligible(a, d->dtype, d->nclass)) return conv_halo_slots(a, d->dtype);
   a.out_f32 = d->out_f32; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo;
   if (conv_up_eligible(a, d->dtype, d->nclass)) return conv_up_tiles(a);
+  a.add = (const char*)d->add; a.o_ld = d->o_ld;
+  if (conv_stem_eligible(a, d->dtype, d->nclass)) return conv_stem_slots(a);
   const int SZq = d->dtype == CTSEG_F32 ? 4 : 2, EPCq = 16 / SZq;
   const bool smallq = (d->Cg % EPCq) != 0 || (d->g_ld % EPCq) != 0 || ((uintptr_t)d->in % 16) != 0;
   const int bm = tile_rows_for(d->Cn, d->dtype, d->out_f32, smallq);

@@ -1,0 +1,402 @@
+// Stem kernels (bf16): the single-channel 3x3x3 stride-2 convolution at the top of the reference's U-Net
+// (Conv3d(1, 32, k3, s2) twice — residual branch and unit0 — fused to 64 columns, capstone/volumetric/base_trainer.py:65-72
+// with in_channels = 1) and its weight gradient.  K = 27: the generic kernel's element-wise gather spends ~1000 VALU
+// instructions per stage on addresses; here a persistent workgroup stages the 9x17x17 input patch of a 4x8x8 output tile
+// in LDS (5 KB), builds each MFMA operand from 8 ds_read_u16, keeps the 27x64 weights in registers, and stores from the
+// accumulators.  Both passes are bound by the 128-byte-per-voxel output / dY stream.
+//
+//   forward : out[v][n] = bias[n] + sum_t in[2v + t - 1] * W[n][t]            (+ InstanceNorm partial sums per workgroup)
+//   wgrad   : R[t][b] = sum_v in[2v + t - 1] * dy[v][b],  R[27][b] = sum_v dy[v][b]   -> 4 slabs per workgroup
+#include "conv_common.h"
+
+namespace ctseg {
+
+constexpr int S_IX = 9, S_IY = 17, S_IZ = 17, S_PZ = 18;          // input patch and its padded z pitch
+constexpr int S_IN = S_IX * S_IY * S_IZ;                           // 2601 elements
+constexpr int S_INB = (S_IX * S_IY * S_PZ * 2 + 15) / 16 * 16;       // bytes of the LDS image, 16-byte aligned (5520)
+constexpr int S_J = (S_IN + 255) / 256;                            // 11 staging slots per thread
+
+__device__ __forceinline__ void stem_patch_voxel(int r16, int& dy, int& z) {
+  dy = (0xEF80u >> r16) & 1;
+  z = (int)((0x2104765437653210ull >> (4 * r16)) & 7ull);
+}
+
+struct StemGeom {
+  int tiles, tyn, tzn;
+};
+
+// shared by both kernels: per-thread staging constants and the patch loader
+struct StemStage {
+  int g_off[S_J], g_xyz[S_J], g_lds[S_J];
+  __device__ __forceinline__ void init(int tid, int Yi, int Zi) {
+#pragma unroll
+    for (int j = 0; j < S_J; ++j) {
+      const int idx = tid + j * 256;
+      const int ix = idx / (S_IY * S_IZ), rem = idx - ix * (S_IY * S_IZ), iy = rem / S_IZ, iz = rem - iy * S_IZ;
+      g_off[j] = ((ix - 1) * Yi + (iy - 1)) * Zi + (iz - 1);
+      g_xyz[j] = idx < S_IN ? (ix | (iy << 8) | (iz << 16)) : 0x7f7f7f;
+      g_lds[j] = ((ix * S_IY + iy) * S_PZ + iz) * 2;
+    }
+  }
+  __device__ __forceinline__ void load(const unsigned short* base, int x0, int y0, int z0, int Xi, int Yi, int Zi,
+                                       unsigned short (&r)[S_J]) const {
+    // base = element pointer of input voxel (2x0, 2y0, 2z0) of the sample
+#pragma unroll
+    for (int j = 0; j < S_J; ++j) {
+      const int xi = 2 * x0 - 1 + (g_xyz[j] & 0xff), yi = 2 * y0 - 1 + ((g_xyz[j] >> 8) & 0xff), zi = 2 * z0 - 1 + (g_xyz[j] >> 16);
+      unsigned short v = 0;
+      if ((unsigned)xi < (unsigned)Xi && (unsigned)yi < (unsigned)Yi && (unsigned)zi < (unsigned)Zi) v = base[g_off[j]];
+      r[j] = v;
+    }
+  }
+  __device__ __forceinline__ void store(char* lds, const unsigned short (&r)[S_J]) const {
+#pragma unroll
+    for (int j = 0; j < S_J; ++j)
+      if ((g_xyz[j] & 0xff) != 0x7f) *reinterpret_cast<unsigned short*>(lds + g_lds[j]) = r[j];
+  }
+};
+
+// LDS element offset of tap t relative to the patch element of output voxel (x,y,z) at tap (0,0,0)
+__device__ __forceinline__ int stem_tap_off(int t) {
+  const int tx = t / 9, ty = (t / 3) % 3, tz = t % 3;
+  return (tx * S_IY + ty) * S_PZ + tz;
+}
+
+template <int NT, bool STATS>
+__global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, int total_tiles, StemGeom G) {
+  constexpr int BN = 16 * NT;
+  __shared__ __attribute__((aligned(16))) char smem[2 * S_INB + 4 * 2 * BN * 4];
+  float* const sStats = reinterpret_cast<float*>(smem + 2 * S_INB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const ctseg_conv_class& K = P.cls[0];
+
+  // weights [rows][kpad = 64]: lane (row r16 of column tile j, quarter q4) holds K elements 8*q4 .. 8*q4+7 (taps; >= 27 are zero)
+  u32x4 wf[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+    wf[j] = *reinterpret_cast<const u32x4*>(P.w + (K.w_off + (int64_t)(j * 16 + r16) * K.kpad) * 2 + q4 * 16);
+  float bias[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = j * 16 + 4 * q4 + e;
+      bias[j][e] = (P.bias != nullptr && ch < P.Cn) ? P.bias[ch] : 0.f;
+    }
+  StemStage stg;
+  stg.init(tid, P.Yi, P.Zi);
+  int pdy, pz;
+  stem_patch_voxel(r16, pdy, pz);
+  int toff[8], abase[4], ovox[4];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) toff[k] = (8 * q4 + k < 27) ? stem_tap_off(8 * q4 + k) * 2 : -1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    abase[i] = (((2 * wave) * S_IY + 2 * (2 * i + pdy)) * S_PZ + 2 * pz) * 2;
+    ovox[i] = (wave * P.Yo + 2 * i + pdy) * P.Zo + pz;
+  }
+  auto origin = [&](int t, int& n, int& x0, int& y0, int& z0) {
+    n = t / G.tiles;
+    int r = t - n * G.tiles;
+    const int tz = r % G.tzn; r /= G.tzn;
+    const int ty = r % G.tyn; const int tx = r / G.tyn;
+    x0 = tx * 4; y0 = ty * 8; z0 = tz * 8;
+  };
+  auto in_base = [&](int n, int x0, int y0, int z0) {
+    return reinterpret_cast<const unsigned short*>(P.in) + (((int64_t)n * P.Xi + 2 * x0) * P.Yi + 2 * y0) * P.Zi + 2 * z0;
+  };
+  float wsum[NT][4], wsq[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { wsum[j][e] = 0.f; wsq[j][e] = 0.f; }
+  int stat_n = -1;
+  auto flush_stats = [&](int n) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = wsum[j][e], b = wsq[j][e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (r16 == 0) {
+          sStats[(wave * 2 + 0) * BN + j * 16 + 4 * q4 + e] = a;
+          sStats[(wave * 2 + 1) * BN + j * 16 + 4 * q4 + e] = b;
+        }
+        wsum[j][e] = 0.f;
+        wsq[j][e] = 0.f;
+      }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, c = tid % BN;
+      const float a = sStats[(0 * 2 + which) * BN + c] + sStats[(1 * 2 + which) * BN + c] + sStats[(2 * 2 + which) * BN + c] +
+                      sStats[(3 * 2 + which) * BN + c];
+      const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + blockIdx.x;
+      P.stats[(slot_t * 2 + which) * P.stats_ld + c] = a;
+    }
+    __syncthreads();
+  };
+
+  unsigned short rg[S_J];
+  int t = blockIdx.x, cur = 0;
+  {
+    int n, x0, y0, z0;
+    if (t < total_tiles) {
+      origin(t, n, x0, y0, z0);
+      stg.load(in_base(n, x0, y0, z0), x0, y0, z0, P.Xi, P.Yi, P.Zi, rg);
+      stg.store(smem, rg);
+    }
+  }
+  __syncthreads();
+  for (; t < total_tiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    int n, x0, y0, z0;
+    if (tn < total_tiles) {
+      origin(tn, n, x0, y0, z0);
+      stg.load(in_base(n, x0, y0, z0), x0, y0, z0, P.Xi, P.Yi, P.Zi, rg);
+    }
+    origin(t, n, x0, y0, z0);
+    if (STATS && n != stat_n) {
+      if (stat_n >= 0) flush_stats(stat_n);
+      stat_n = n;
+    }
+    const char* h = smem + cur * S_INB;
+    const int64_t vb = (((int64_t)n * P.Xo + x0) * P.Yo + y0) * P.Zo + z0;
+    const bool xok = x0 + wave < P.Xr, zok = z0 + pz < P.Zr;
+    char* ob = P.out + vb * P.o_ld * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // K = 32 is ONE MFMA per 16x16 tile: operand -> MFMA -> store, row tile by row tile
+      u32x4 xf;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t lo = toff[2 * k] >= 0 ? *reinterpret_cast<const unsigned short*>(h + abase[i] + toff[2 * k]) : 0u;
+        const uint32_t hi = toff[2 * k + 1] >= 0 ? *reinterpret_cast<const unsigned short*>(h + abase[i] + toff[2 * k + 1]) : 0u;
+        xf[k] = lo | (hi << 16);
+      }
+      const bool rv = xok && zok && (y0 + 2 * i + pdy < P.Yr);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        mma16<BF16>(acc, wf[j], xf);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[e] + bias[j][e];
+          if (STATS && rv) { wsum[j][e] += v[e]; wsq[j][e] += v[e] * v[e]; }
+        }
+        const int ch = j * 16 + 4 * q4;
+        if (rv && ch < P.Cn_store)
+          *reinterpret_cast<u32x2*>(ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      }
+    }
+    if (tn < total_tiles) stg.store(smem + (cur ^ 1) * S_INB, rg);
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (STATS && stat_n >= 0) flush_stats(stat_n);
+}
+
+bool conv_stem_eligible(const ConvKArgs& a, int dtype, int nclass) {
+  if (dtype != CTSEG_BF16 || nclass != 1 || a.Cg != 1 || a.g_ld != 1 || a.sin != 2 || a.sout != 1 || a.out_f32 || a.add) return false;
+  if (a.cls[0].ntaps != 27 || a.cls[0].kpad != 64 || a.Cn > 64 || a.Cn % 16 != 0 || a.Zr < 4) return false;
+  if (a.Xi != 2 * a.Xr || a.Yi != 2 * a.Yr || a.Zi != 2 * a.Zr) return false;
+  if ((int64_t)a.Xi * a.Yi * a.Zi >= (1ll << 31) || (int64_t)a.Xo * a.Yo * a.Zo * a.o_ld * 2 >= (1ll << 31)) return false;
+  for (int j = 0; j < 27; ++j) {   // taps must be the plain conv's, in torch order: offset = t - 1 per axis
+    const int tp = a.cls[0].taps[j];
+    const int ex = j / 9 - 1, ey = (j / 3) % 3 - 1, ez = j % 3 - 1;
+    if ((int)(int8_t)(tp & 0xff) != ex || (int)(int8_t)((tp >> 8) & 0xff) != ey || (int)(int8_t)((tp >> 16) & 0xff) != ez) return false;
+  }
+  return true;
+}
+
+static int stem_tiles(int Xr, int Yr, int Zr) { return ((Xr + 3) / 4) * ((Yr + 7) / 8) * ((Zr + 7) / 8); }
+static int stem_grid(int total) { return total < 1024 ? total : 1024; }
+int conv_stem_slots(const ConvKArgs& a) { return stem_grid(stem_tiles(a.Xr, a.Yr, a.Zr) * a.N); }
+
+void launch_conv_stem(ConvKArgs& a, hipStream_t st) {
+  StemGeom g;
+  g.tiles = stem_tiles(a.Xr, a.Yr, a.Zr); g.tyn = (a.Yr + 7) / 8; g.tzn = (a.Zr + 7) / 8;
+  a.tiles = g.tiles;
+  const int total = g.tiles * a.N, grid = stem_grid(total);
+  const int nt = (a.Cn + 15) / 16;
+#define CTSEG_STEM(NTV)                                                                                               \
+  do {                                                                                                              \
+    if (a.stats != nullptr) hipLaunchKernelGGL((conv_stem_fwd_kernel<NTV, true>), dim3(grid), dim3(256), 0, st, a, total, g); \
+    else hipLaunchKernelGGL((conv_stem_fwd_kernel<NTV, false>), dim3(grid), dim3(256), 0, st, a, total, g);          \
+  } while (0)
+  if (nt == 1) CTSEG_STEM(1);
+  else if (nt == 2) CTSEG_STEM(2);
+  else if (nt == 3) CTSEG_STEM(3);
+  else CTSEG_STEM(4);
+#undef CTSEG_STEM
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// weight gradient: R[32 rows = taps (row 27 = ones)][16*CT columns]; wave w owns k-steps 2w, 2w+1 of every tile
+// ---------------------------------------------------------------------------------------------------------------------------
+struct StemWgradArgs {
+  const char* in;
+  const char* dy;
+  float* ws;
+  int N, Xi, Yi, Zi, Xr, Yr, Zr, d_ld, kpad_w, cn_pad;
+  StemGeom G;
+};
+
+template <int CT>
+__global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArgs P, int total_tiles) {
+  constexpr int DBYTES = CT * 256 * 32, DCH = 256 * CT * 2, JD = DCH / 256;   // dy tile: planes of 16 channels, 32 B per voxel
+  constexpr int BUF = S_INB + DBYTES;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef s16x4 __attribute__((address_space(3)))* lds_s16x4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF + 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q4 = lane >> 4, tq = r16 >> 2, tp = r16 & 3;
+
+  StemStage stg;
+  stg.init(tid, P.Yi, P.Zi);
+  const int YZ = P.Yr * P.Zr;
+  int gd_byte[JD], gd_xyz[JD], gd_lds[JD];
+#pragma unroll
+  for (int j = 0; j < JD; ++j) {
+    const int idx = tid + j * 256;
+    const int c = idx % (2 * CT), tv = idx / (2 * CT);
+    const int tx = tv >> 6, ty = (tv >> 3) & 7, tz = tv & 7;
+    gd_byte[j] = ((tx * YZ + ty * P.Zr + tz) * P.d_ld + c * 8) * 2;
+    gd_xyz[j] = tx | (ty << 8) | (tz << 16);
+    gd_lds[j] = (c >> 1) * (256 * 32) + tv * 32 + (c & 1) * 16;
+  }
+  auto origin = [&](int t, int& n, int& x0, int& y0, int& z0) {
+    n = t / P.G.tiles;
+    int r = t - n * P.G.tiles;
+    const int tz = r % P.G.tzn; r /= P.G.tzn;
+    const int ty = r % P.G.tyn; const int tx = r / P.G.tyn;
+    x0 = tx * 4; y0 = ty * 8; z0 = tz * 8;
+  };
+  unsigned short rg[S_J];
+  u32x4 rd[JD];
+  auto gload = [&](int t) {
+    int n, x0, y0, z0;
+    origin(t, n, x0, y0, z0);
+    const unsigned short* ib = reinterpret_cast<const unsigned short*>(P.in) + (((int64_t)n * P.Xi + 2 * x0) * P.Yi + 2 * y0) * P.Zi + 2 * z0;
+    stg.load(ib, x0, y0, z0, P.Xi, P.Yi, P.Zi, rg);
+    const char* db = P.dy + ((((int64_t)n * P.Xr + x0) * P.Yr + y0) * P.Zr + z0) * P.d_ld * 2;
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+      const int xi = x0 + (gd_xyz[j] & 0xff), yi = y0 + ((gd_xyz[j] >> 8) & 0xff), zi = z0 + (gd_xyz[j] >> 16);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (xi < P.Xr && yi < P.Yr && zi < P.Zr) v = *reinterpret_cast<const u32x4*>(db + gd_byte[j]);
+      rd[j] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+    char* b = smem + buf * BUF;
+    stg.store(b, rg);
+#pragma unroll
+    for (int j = 0; j < JD; ++j) *reinterpret_cast<u32x4*>(b + S_INB + gd_lds[j]) = rd[j];
+  };
+
+  // A' operand: row = tap (r16 [+16]), k = voxel (y-row 2r + (q4>>1), z = 4*(q4&1) + j) of the k-step, as in conv_wgrad_halo
+  int toffA[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int tap = a * 16 + r16;
+    toffA[a] = tap < 27 ? stem_tap_off(tap) * 2 : (tap == 27 ? -2 : -1);     // -2: all-ones row (bias gradient), -1: zero row
+  }
+  f32x4 acc[2][CT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int t = blockIdx.x, cur = 0;
+  if (t < total_tiles) {
+    gload(t);
+    sstore(0);
+  }
+  __syncthreads();
+  for (; t < total_tiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    if (tn < total_tiles) gload(tn);
+    const char* xs = smem + cur * BUF;
+    const char* ds = xs + S_INB;
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const int s = 2 * wave + ss, x = s >> 1, yb = 4 * (s & 1);
+      const int ly = q4 >> 1, lz0 = 4 * (q4 & 1);
+      bf16x8 df[CT];
+#pragma unroll
+      for (int b = 0; b < CT; ++b) {
+        const char* p0 = ds + b * (256 * 32) + (((x * 8) + (yb + ly)) * 8 + lz0 + tq) * 32 + tp * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 2 * 8 * 32));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        df[b] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        s16x8 av;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // voxel of k index 8*q4 + j: y = yb + 2*(j>>2) + ly, z = lz0 + (j&3)
+          const int y = yb + 2 * (j >> 2) + ly, z = lz0 + (j & 3);
+          short val = 0;
+          if (toffA[a] >= 0) val = *reinterpret_cast<const short*>(xs + (((2 * x) * S_IY + 2 * y) * S_PZ + 2 * z) * 2 + toffA[a]);
+          else if (toffA[a] == -2) val = (short)0x3f80;
+          av[j] = val;
+        }
+        const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+        for (int b = 0; b < CT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, df[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (tn < total_tiles) sstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  // one slab per wave: rows 4*q4+e (+16a) = tap, column b*16 + r16
+  float* slab = P.ws + ((int64_t)blockIdx.x * 4 + wave) * P.kpad_w * P.cn_pad;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < CT; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) slab[(int64_t)(a * 16 + 4 * q4 + e) * P.cn_pad + b * 16 + r16] = acc[a][b][e];
+}
+
+bool wgrad_stem_eligible(const ctseg_wgrad_desc* d) {
+  if (d->dtype != CTSEG_BF16 || d->ntaps != 27 || d->sin != 2 || d->Cg != 1 || d->g_ld != 1) return false;
+  if (d->Cn > 64 || d->Cn % 16 != 0 || d->d_ld % 8 != 0 || d->d_ld < d->Cn || ((uintptr_t)d->dy % 16) != 0) return false;
+  if (d->Xi != 2 * d->Xr || d->Yi != 2 * d->Yr || d->Zi != 2 * d->Zr || d->Zr < 4) return false;
+  if (d->kpad_w < 32 || d->cn_pad < d->Cn) return false;
+  if ((int64_t)d->Xi * d->Yi * d->Zi >= (1ll << 31) || (int64_t)d->Xr * d->Yr * d->Zr * d->d_ld * 2 >= (1ll << 31)) return false;
+  for (int j = 0; j < 27; ++j) {
+    const int tp = d->taps[j];
+    const int ex = j / 9 - 1, ey = (j / 3) % 3 - 1, ez = j % 3 - 1;
+    if ((int)(int8_t)(tp & 0xff) != ex || (int)(int8_t)((tp >> 8) & 0xff) != ey || (int)(int8_t)((tp >> 16) & 0xff) != ez) return false;
+  }
+  return true;
+}
+
+static int wgrad_stem_grid(const ctseg_wgrad_desc* d) {
+  const int total = stem_tiles(d->Xr, d->Yr, d->Zr) * d->N;
+  return total < 512 ? total : 512;
+}
+int wgrad_stem_slabs(const ctseg_wgrad_desc* d) { return 4 * wgrad_stem_grid(d); }
+
+void launch_wgrad_stem(const ctseg_wgrad_desc* d, hipStream_t st) {
+  StemWgradArgs a;
+  a.in = (const char*)d->in; a.dy = (const char*)d->dy; a.ws = d->ws;
+  a.N = d->N; a.Xi = d->Xi; a.Yi = d->Yi; a.Zi = d->Zi; a.Xr = d->Xr; a.Yr = d->Yr; a.Zr = d->Zr;
+  a.d_ld = d->d_ld; a.kpad_w = d->kpad_w; a.cn_pad = d->cn_pad;
+  a.G.tiles = stem_tiles(d->Xr, d->Yr, d->Zr); a.G.tyn = (d->Yr + 7) / 8; a.G.tzn = (d->Zr + 7) / 8;
+  const int total = a.G.tiles * d->N, grid = wgrad_stem_grid(d);
+  const int ct = d->Cn / 16;
+  if (ct == 1) hipLaunchKernelGGL((conv_stem_wgrad_kernel<1>), dim3(grid), dim3(256), 0, st, a, total);
+  else if (ct == 2) hipLaunchKernelGGL((conv_stem_wgrad_kernel<2>), dim3(grid), dim3(256), 0, st, a, total);
+  else if (ct == 3) hipLaunchKernelGGL((conv_stem_wgrad_kernel<3>), dim3(grid), dim3(256), 0, st, a, total);
+  else hipLaunchKernelGGL((conv_stem_wgrad_kernel<4>), dim3(grid), dim3(256), 0, st, a, total);
+}
+
+}  // namespace ctseg

@@ -272,6 +272,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int nslabs, in
   }
 }
 
+bool wgrad_stem_eligible(const ctseg_wgrad_desc* d);
+int wgrad_stem_slabs(const ctseg_wgrad_desc* d);
+void launch_wgrad_stem(const ctseg_wgrad_desc* d, hipStream_t st);
 bool wgrad_halo_eligible(const ctseg_wgrad_desc* d);
 int wgrad_halo_slabs(const ctseg_wgrad_desc* d);
 void launch_wgrad_halo(const ctseg_wgrad_desc* d, hipStream_t st);
@@ -295,6 +298,7 @@ extern "C" int ctseg_wgrad_tile_cols(int32_t Cn) { return Cn <= 16 ? 16 : Cn <= 
 extern "C" int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d) {
   if (d == nullptr) return -1;
   if (wgrad_halo_eligible(d)) return wgrad_halo_slabs(d);
+  if (wgrad_stem_eligible(d)) return wgrad_stem_slabs(d);
   return d->N * d->splits;
 }
 
@@ -311,6 +315,11 @@ extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
     CTSEG_REQUIRE(d->kpad_w >= ktot + 16 && d->cn_pad >= ((d->Cn + 15) / 16) * 16, "conv_wgrad: slab too small for the halo kernel");
     launch_wgrad_halo(d, (hipStream_t)stream);
     CTSEG_LAUNCH_CHECK("conv_wgrad_halo");
+    return 0;
+  }
+  if (wgrad_stem_eligible(d)) {
+    launch_wgrad_stem(d, (hipStream_t)stream);
+    CTSEG_LAUNCH_CHECK("conv_wgrad_stem");
     return 0;
   }
   CTSEG_REQUIRE(d->kpad_w % 128 == 0 && d->kpad_w >= ktot + 1, "conv_wgrad: kpad_w %d (K=%d)", d->kpad_w, ktot);

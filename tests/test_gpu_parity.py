@@ -99,6 +99,23 @@ def test_up_halo_kernel_vs_torch_cpu(kind, cin, cout, shape):
     assert rel_err(gb, mod.bias.grad) < 2.5e-2, "bias gradient"
 
 
+@pytest.mark.parametrize("cout,shape", [(16, (1, 16, 16, 8)), (64, (2, 8, 16, 16)), (32, (1, 10, 12, 8)), (48, (1, 8, 8, 24))])
+def test_stem_kernels_vs_torch_cpu(cout, shape):
+    """single-channel 3x3x3 stride-2 conv (conv_stem.hip: forward with LDS input patch, weight gradient with 4 slabs per
+    workgroup), bf16, ragged tiles included."""
+    torch.manual_seed(cout)
+    mod = torch.nn.Conv3d(1, cout, 3, 2, 1)
+    x = torch.randn(shape[0], 1, *shape[1:])
+    y = mod(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yy, gx, gw, gb = run_conv_module(mod, x, gy, BF16, DEV)
+    assert gx is None
+    assert rel_err(yy, y.detach()) < 2.5e-2, "forward"
+    assert rel_err(gw, mod.weight.grad) < 2.5e-2, "weight gradient"
+    assert rel_err(gb, mod.bias.grad) < 2.5e-2, "bias gradient"
+
+
 @pytest.mark.parametrize("dt,tol", [(F32, 1e-5), (BF16, 2e-2)])
 def test_instnorm_prelu_fwd_bwd(golden, dt, tol):
     """conv-epilogue statistics -> finalize -> apply, and the 3-kernel backward, against InstanceNorm3d+PReLU."""
