@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--shape", type=int, nargs=4, default=[2, 512, 512, 48], metavar=("B", "H", "W", "D"))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-shape", type=int, nargs=4, default=[1, 256, 256, 48])   # a quarter of one volume: bounded sample
+    ap.add_argument("--cpu-shape", type=int, nargs=4, default=[1, 512, 512, 48])   # one volume = half a batch: ~10 s on 16 host threads
     args = ap.parse_args()
 
     from capstone_amd import distributed as cdist
