@@ -27,6 +27,9 @@ template <int BM, int BN, int CSZ = 4> struct ConvSmem {
   static constexpr int TOTAL = MAIN + STATS + ROWTAB + 64 * 4;
 };
 
+// 16 zero bytes in device memory: the source of padded (out-of-tensor) operand chunks for direct-to-LDS loads
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
 template <typename T, int BM, int BN, int WGM, int WGN, bool SMALLC>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvKArgs P) {
   constexpr int NTHR = 64 * WGM * WGN;     // 4 waves, or 8 for the 192x256 bf16 tile (never fp32 output: CSZ = 2)
@@ -75,7 +78,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvKA
   }
   __syncthreads();
 
-  const int q8 = tid % CH, r0 = tid / CH;
+  constexpr bool GLDS = (NTHR == 512) && !SMALLC;   // 8-wave tile: global_load_lds (no VGPR staging, no ds_write pass)
+  const int q8s = tid % CH, r0 = tid / CH;
+  // with direct-to-LDS loads the LDS image is lane-linear (slot = tid % 8), so the XOR swizzle is applied to WHICH K chunk a
+  // lane fetches instead (rule: linear destination + swizzled source + swizzled read); RPR is a multiple of 16 -> same for all j
+  const int q8 = GLDS ? (q8s ^ ((r0 >> 1) & 7)) : q8s;
   int rxy[AR], rz[AR];
 #pragma unroll
   for (int j = 0; j < AR; ++j) {
@@ -105,12 +112,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvKA
     }
     rmask[j] = m;
     const int r = r0 + j * RPR;
-    soffA[j] = r * BKB + ((q8 ^ ((r >> 1) & 7)) << 4);
+    soffA[j] = r * BKB + ((q8s ^ ((r >> 1) & 7)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < BR; ++j) {
     const int r = r0 + j * RPR;
-    soffB[j] = r * BKB + ((q8 ^ ((r >> 1) & 7)) << 4);
+    soffB[j] = r * BKB + ((q8s ^ ((r >> 1) & 7)) << 4);
   }
   const char* wrow = P.w + (K.w_off + (int64_t)(col0 + r0) * kpad + q8 * EPC) * SZ;
 
@@ -180,6 +187,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvKA
       if (BN >= RPR || r0 + j * RPR < BN) *reinterpret_cast<u32x4*>(b + soffB[j]) = rb[j];
   };
 
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto gload_lds = [&](int s, int buf) {   // GLDS only: each wave instruction fills 8 rows x 128 B = 1 KiB of LDS, lane-linear
+    const bool sv = slot < ntaps;
+    const int tp = sv ? sTap[slot & 31] : 0;
+    const int tb = (sv ? sTap[32 + (slot & 31)] : 0) + ci * SZ;
+    const int sx = (int)(int8_t)(tp & 0xff) + 1, sy = (int)(int8_t)((tp >> 8) & 0xff) + 4, sz = (int)(int8_t)((tp >> 16) & 0xff) + 7;
+    char* a = sA0 + buf * BM * BKB + (wave * 8) * BKB;
+    char* b = sB0 + buf * BN * BKB + (wave * 8) * BKB;
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+      const bool ok = sv && (((rmask[j] >> sx) & (rmask[j] >> sy) & (rmask[j] >> sz) & 1) != 0);
+      const char* src = ok ? (P.in + rowb[j] + tb) : reinterpret_cast<const char*>(g_zero16);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a + j * RPR * BKB), 16, 0, 0);
+    }
+    ci += BK;
+    while (ci >= P.Cg) { ci -= P.Cg; ++slot; }
+#pragma unroll
+    for (int j = 0; j < BR; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wrow + ((int64_t)j * RPR * kpad + (int64_t)s * BK) * SZ), (lptr_t)(b + j * RPR * BKB), 16, 0, 0);
+  };
+
   f32x4 acc[NT][MT];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
@@ -205,23 +234,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvKA
         for (int i = 0; i < MT; ++i) mma16<T>(acc[j][i], wf[j], xf[i]);
     }
   };
-  if constexpr (NTHR == 512) {
-    // 8-wave tile, ONE workgroup per CU: nothing else hides the load latency, so keep two stages in flight (two
-    // register sets; stage s+2 is requested while stage s computes)
-    u32x4 ra1[AR], rb1[BR];
-    gload(0, ra0, rb0);
-    sstore(0, ra0, rb0);
-    if (nst > 1) gload(1, ra1, rb1);
+  if constexpr (GLDS) {
+    // 8-wave tile, ONE workgroup per CU: stage s+1 streams straight into the other LDS buffer while stage s computes;
+    // __syncthreads() waits for the DMA (hipcc emits vmcnt(0) for pending LDS-DMA) and for every wave's reads of `buf`
+    gload_lds(0, 0);
     __syncthreads();
-    for (int s = 0; s < nst; s += 2) {
-      if (s + 2 < nst) gload(s + 2, ra0, rb0);
-      compute(0);
-      if (s + 1 < nst) sstore(1, ra1, rb1);
-      __syncthreads();
-      if (s + 1 >= nst) break;
-      if (s + 3 < nst) gload(s + 3, ra1, rb1);
-      compute(1);
-      if (s + 2 < nst) sstore(0, ra0, rb0);
+    for (int s = 0; s < nst; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nst) gload_lds(s + 1, buf ^ 1);
+      compute(buf);
       __syncthreads();
     }
   } else {
