@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvKA
   }
   __syncthreads();
 
-  constexpr bool GLDS = (NTHR == 512) && !SMALLC;   // 8-wave tile: global_load_lds (no VGPR staging, no ds_write pass)
+  constexpr bool GLDS = !SMALLC;   // global_load_lds: no VGPR staging, no ds_write pass (element-wise stem gather excepted)
   const int q8s = tid % CH, r0 = tid / CH;
   // with direct-to-LDS loads the LDS image is lane-linear (slot = tid % 8), so the XOR swizzle is applied to WHICH K chunk a
   // lane fetches instead (rule: linear destination + swizzled source + swizzled read); RPR is a multiple of 16 -> same for all j
@@ -206,7 +206,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvKA
     while (ci >= P.Cg) { ci -= P.Cg; ++slot; }
 #pragma unroll
     for (int j = 0; j < BR; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wrow + ((int64_t)j * RPR * kpad + (int64_t)s * BK) * SZ), (lptr_t)(b + j * RPR * BKB), 16, 0, 0);
+      if (BN >= RPR || wave * 8 + j * RPR < BN)   // wave-uniform: a 16-column tile only has rows for the first two waves
+        __builtin_amdgcn_global_load_lds((gptr_t)(wrow + ((int64_t)j * RPR * kpad + (int64_t)s * BK) * SZ), (lptr_t)(b + j * RPR * BKB), 16, 0, 0);
   };
 
   f32x4 acc[NT][MT];
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvKA
     }
   };
   if constexpr (GLDS) {
-    // 8-wave tile, ONE workgroup per CU: stage s+1 streams straight into the other LDS buffer while stage s computes;
+    // stage s+1 streams straight into the other LDS buffer while stage s computes;
     // __syncthreads() waits for the DMA (hipcc emits vmcnt(0) for pending LDS-DMA) and for every wave's reads of `buf`
     gload_lds(0, 0);
     __syncthreads();
