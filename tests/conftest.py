@@ -14,6 +14,11 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the shared library is a build artefact (git-ignored): build it in-tree when a fresh checkout runs the tests first
+    lib = os.path.join(PKG, "lib", "libctseg_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "-C", PKG, "-j4"], stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
