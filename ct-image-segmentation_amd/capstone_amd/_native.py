@@ -90,6 +90,8 @@ _SIGS = {
     "ctseg_cast": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp]),
     "ctseg_nc_to_cl": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     "ctseg_cl_to_nc": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
+    "ctseg_window_gather": (C.c_int, [_vp] + [_i32] * 10 + [_f32, _vp, _i32, _i32, _vp]),
+    "ctseg_window_blend": (C.c_int, [_vp] + [_i32] * 8 + [_vp, _vp, _vp] + [_i32] * 4 + [_vp]),
 }
 EXPORTS = tuple(_SIGS)
 _lib = None

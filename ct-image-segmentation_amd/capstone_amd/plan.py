@@ -245,8 +245,9 @@ class _Level:
 
 
 class Plan:
-    def __init__(self, engine, N, X, Y, Z):
+    def __init__(self, engine, N, X, Y, Z, inference=False):
         net = engine.net
+        self.inference = inference        # forward program only: no gradient buffers, no backward program
         self.engine, self.store, self.dt, self.device = engine, engine.store, engine.dt, engine.device
         self.dims = net.dimensions
         self.need_input_grad = False
@@ -263,9 +264,10 @@ class Plan:
         self._cur = self.fwd
         self.logits = self.root.emit_fwd(self.x, out_f32=True)
         assert self.logits.t.dtype == torch.float32
-        self.dlogits = new_act(*self.logits.dims, net.out_channels, self.dt, self.device)
-        self._cur = self.bwd
-        self.root.emit_bwd(self.dlogits, need_dx=False)
+        if not inference:
+            self.dlogits = new_act(*self.logits.dims, net.out_channels, self.dt, self.device)
+            self._cur = self.bwd
+            self.root.emit_bwd(self.dlogits, need_dx=False)
         self._cur = None
 
     # ---- recording ----
@@ -308,14 +310,18 @@ class Plan:
             xs = xs.contiguous().float()
         nat.call("ctseg_nc_to_cl", xs.data_ptr(), self.x.t.data_ptr(), self.dt, N, cin, X * Y * Z, cin)
 
-    def forward(self, x):
-        self.load_input(x)
+    def forward(self, x=None):
+        """x = None: the caller already filled ``self.x`` (sliding-window gather writes it directly)"""
+        if x is not None:
+            self.load_input(x)
         self.packer.refresh()
         self.run(self.fwd, nat.stream_ptr())
         return self.logits
 
     def backward(self, hooks=None):
         """runs the recorded backward; ``hooks`` = {program index: callable} fire between ops (DDP overlap)"""
+        if self.inference:
+            raise RuntimeError("this plan was recorded for inference (torch.no_grad()); run the forward with gradients enabled first")
         st = nat.stream_ptr()
         if not hooks:
             self.run(self.bwd, st)
@@ -372,21 +378,27 @@ class Engine:
             self.store.attach()
         return self.store
 
-    def plan_for(self, x):
-        self.ensure(x.device)
-        nd = self.net.dimensions
-        if x.ndim != nd + 2 or x.shape[1] != self.net.in_channels:
+    def plan_for(self, x, inference=False):
+        if x.ndim != self.net.dimensions + 2 or x.shape[1] != self.net.in_channels:
+            nd = self.net.dimensions
             raise ValueError(f"expected input (B,{self.net.in_channels},{'H,W,D' if nd == 3 else 'H,W'}), got {tuple(x.shape)}")
-        N, sp = x.shape[0], tuple(x.shape[2:]) + ((1,) if nd == 2 else ())
+        return self.plan_for_shape(x.device, x.shape[0], tuple(x.shape[2:]), inference)
+
+    def plan_for_shape(self, device, N, spatial, inference=False):
+        """``inference`` plans hold no backward buffers; an existing training plan of the same shape is reused instead"""
+        self.ensure(device)
+        nd = self.net.dimensions
+        sp = tuple(spatial) + ((1,) if nd == 2 else ())
         nlev = len(self.net.channels) - 1
         for v in sp[:nd]:
             if v % (2 ** nlev):
                 raise ValueError(f"spatial size {v} is not divisible by 2^{nlev} (the skip concat needs it, as in MONAI)")
         key = (N,) + sp
-        if key not in self.plans:
-            self.plans[key] = Plan(self, N, *sp)
-        self.last_plan = self.plans[key]
-        return self.last_plan
+        plan = self.plans.get(key) or (self.plans.get(key + ("inference",)) if inference else None)
+        if plan is None:
+            plan = self.plans[key + (("inference",) if inference else ())] = Plan(self, N, *sp, inference=inference)
+        self.last_plan = plan
+        return plan
 
     # ---- raw (no autograd) API used by the native training step, bench and tests ----
     def forward(self, x):
@@ -402,9 +414,10 @@ class Engine:
 
     # ---- autograd surface (drop-in for loss.backward()) ----
     def forward_autograd(self, x):
-        plan = self.plan_for(x)
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters())
+        plan = self.plan_for(x, inference=not train)
         params = self.store.params
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if train:
             if x.requires_grad:
                 raise NotImplementedError("gradient w.r.t. the input image is not implemented (the reference never needs it)")
             return _UNetFn.apply(x, self, plan, *params)

@@ -82,6 +82,40 @@ template <typename TS> __global__ void cl_to_nc_kernel(const TS* __restrict__ s,
   }
 }
 
+// ---- sliding-window inference (semantics of MONAI's sliding_window_inference) ----
+// one window per launch: windows of a batch may overlap, stream order makes the accumulation deterministic
+template <typename TD>
+__global__ void window_gather_kernel(const float* __restrict__ vol, int Cin, int X, int Y, int Z, int x0, int y0, int z0, int rx,
+                                     int ry, int rz, float cval, TD* __restrict__ dst, int ld) {
+  const int64_t total = (int64_t)rx * ry * rz * ld;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / ld;
+    const int c = (int)(i - v * ld);
+    const int z = (int)(v % rz), y = (int)((v / rz) % ry), x = (int)(v / ((int64_t)rz * ry));
+    const int gx = x0 + x, gy = y0 + y, gz = z0 + z;
+    float val = 0.f;
+    if (c < Cin) {
+      const bool in = (unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y && (unsigned)gz < (unsigned)Z;
+      val = in ? vol[(((int64_t)c * X + gx) * Y + gy) * Z + gz] : cval;
+    }
+    dst[i] = cvt<float, TD>(val);
+  }
+}
+__global__ void window_blend_kernel(const float* __restrict__ logits, int ld, int C, int rx, int ry, int rz, int x0, int y0, int z0,
+                                    const float* __restrict__ imp, const float* __restrict__ inv_count, float* __restrict__ out,
+                                    int X, int Y, int Z, int out_ld) {
+  const int64_t total = (int64_t)rx * ry * rz * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / C;
+    const int c = (int)(i - v * C);
+    const int z = (int)(v % rz), y = (int)((v / rz) % ry), x = (int)(v / ((int64_t)rz * ry));
+    const int gx = x0 + x, gy = y0 + y, gz = z0 + z;
+    if ((unsigned)gx >= (unsigned)X || (unsigned)gy >= (unsigned)Y || (unsigned)gz >= (unsigned)Z) continue;   // padded rim
+    const int64_t d = ((int64_t)gx * Y + gy) * Z + gz;
+    out[d * out_ld + c] += imp[v] * (inv_count ? inv_count[d] : 1.f) * logits[v * ld + c];
+  }
+}
+
 static inline unsigned nblocks(int64_t total, int cap = 4096) {
   int64_t b = (total + 255) / 256;
   return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
@@ -153,5 +187,29 @@ extern "C" int ctseg_cl_to_nc(const void* src, int32_t dtype, float* dst, int32_
   if (dtype == CTSEG_F32) hipLaunchKernelGGL(cl_to_nc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, C, S, ld);
   else hipLaunchKernelGGL(cl_to_nc_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src, dst, C, S, ld);
   CTSEG_LAUNCH_CHECK("cl_to_nc");
+  return 0;
+}
+
+extern "C" int ctseg_window_gather(const float* vol, int32_t Cin, int32_t X, int32_t Y, int32_t Z, int32_t x0, int32_t y0, int32_t z0,
+                                   int32_t rx, int32_t ry, int32_t rz, float cval, void* dst, int32_t dtype, int32_t ld, void* stream) {
+  CTSEG_REQUIRE(vol && dst && Cin > 0 && ld >= Cin && X > 0 && Y > 0 && Z > 0 && rx > 0 && ry > 0 && rz > 0, "window_gather: bad arguments");
+  dim3 grid(nblocks((int64_t)rx * ry * rz * ld));
+  if (dtype == CTSEG_F32)
+    hipLaunchKernelGGL(window_gather_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, vol, Cin, X, Y, Z, x0, y0, z0, rx, ry, rz, cval, (float*)dst, ld);
+  else
+    hipLaunchKernelGGL(window_gather_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, vol, Cin, X, Y, Z, x0, y0, z0, rx, ry, rz, cval,
+                       (unsigned short*)dst, ld);
+  CTSEG_LAUNCH_CHECK("window_gather");
+  return 0;
+}
+
+extern "C" int ctseg_window_blend(const float* logits, int32_t ld, int32_t C, int32_t rx, int32_t ry, int32_t rz, int32_t x0, int32_t y0,
+                                  int32_t z0, const float* importance, const float* inv_count, float* out, int32_t X, int32_t Y, int32_t Z,
+                                  int32_t out_ld, void* stream) {
+  CTSEG_REQUIRE(logits && importance && out && C > 0 && ld >= C && out_ld >= C && X > 0 && Y > 0 && Z > 0 && rx > 0 && ry > 0 &&
+                    rz > 0, "window_blend: bad arguments");
+  hipLaunchKernelGGL(window_blend_kernel, dim3(nblocks((int64_t)rx * ry * rz * C)), dim3(256), 0, (hipStream_t)stream, logits, ld, C, rx, ry, rz,
+                     x0, y0, z0, importance, inv_count, out, X, Y, Z, out_ld);
+  CTSEG_LAUNCH_CHECK("window_blend");
   return 0;
 }

@@ -163,6 +163,20 @@ int ctseg_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype,
 int ctseg_nc_to_cl(const float* src, void* dst, int32_t dtype, int32_t N, int32_t C, int64_t S, int32_t ld, void* stream);
 int ctseg_cl_to_nc(const void* src, int32_t dtype, float* dst, int32_t N, int32_t C, int64_t S, int32_t ld, void* stream);
 
+/* Sliding-window inference (BASELINE.json configs[4]).  The reference has no inferer (grep: 0 hits); the
+ * semantics are those of MONAI 0.3 `monai.inferers.sliding_window_inference`, the companion of the `monai.networks.nets.UNet`
+ * the reference builds at capstone/volumetric/base_trainer.py:65-72.
+ *  gather: vol fp32 [Cin][X][Y][Z] -> dst dtype [rx][ry][rz][ld] = the window at (x0,y0,z0); voxels outside the volume = cval
+ *          (MONAI pads volumes smaller than the ROI; starts may be negative), pad channels = 0.
+ *  blend : out[x0+x][y0+y][z0+z][c] += importance[x][y][z] * inv_count[dst voxel] * logits[x][y][z][c] for voxels inside
+ *          the volume (inv_count == NULL: factor 1 — used to accumulate the weight sum itself); one window per launch, so
+ *          overlapping windows accumulate in stream order (deterministic). */
+int ctseg_window_gather(const float* vol, int32_t Cin, int32_t X, int32_t Y, int32_t Z, int32_t x0, int32_t y0, int32_t z0,
+                        int32_t rx, int32_t ry, int32_t rz, float cval, void* dst, int32_t dtype, int32_t ld, void* stream);
+int ctseg_window_blend(const float* logits, int32_t ld, int32_t C, int32_t rx, int32_t ry, int32_t rz, int32_t x0, int32_t y0,
+                       int32_t z0, const float* importance, const float* inv_count, float* out, int32_t X, int32_t Y, int32_t Z,
+                       int32_t out_ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

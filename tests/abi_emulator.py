@@ -273,6 +273,36 @@ class Emulator:
         s = mem(src, N * S * ld).reshape(N, S, ld)
         mem(dst, N * C * S).reshape(N, C, S)[:] = np.transpose(s[..., :C], (0, 2, 1))
 
+    def window_gather(self, vol, Cin, X, Y, Z, x0, y0, z0, rx, ry, rz, cval, dst, dtype, ld):
+        assert dtype == F32
+        v = mem(vol, Cin * X * Y * Z).reshape(Cin, X, Y, Z)
+        d = mem(dst, rx * ry * rz * ld).reshape(rx, ry, rz, ld)
+        d[:] = 0
+        d[..., :Cin] = np.float32(cval)
+        xs, ys, zs = (np.arange(r) + o for r, o in ((rx, x0), (ry, y0), (rz, z0)))
+        ix, iy, iz = (np.nonzero((a >= 0) & (a < n))[0] for a, n in ((xs, X), (ys, Y), (zs, Z)))
+        if len(ix) and len(iy) and len(iz):
+            sub = v[:, xs[ix][0]:xs[ix][-1] + 1, ys[iy][0]:ys[iy][-1] + 1, zs[iz][0]:zs[iz][-1] + 1]
+            d[ix[0]:ix[-1] + 1, iy[0]:iy[-1] + 1, iz[0]:iz[-1] + 1, :Cin] = np.moveaxis(sub, 0, -1)
+
+    def window_blend(self, logits, ld, C, rx, ry, rz, x0, y0, z0, imp, inv_count, out, X, Y, Z, out_ld):
+        l = mem(logits, rx * ry * rz * ld).reshape(rx, ry, rz, ld)
+        w = mem(imp, rx * ry * rz).reshape(rx, ry, rz)
+        ic = mem(inv_count, X * Y * Z).reshape(X, Y, Z) if inv_count else np.ones((X, Y, Z), np.float32)
+        o = mem(out, X * Y * Z * out_ld).reshape(X, Y, Z, out_ld)
+        for x in range(rx):
+            gx = x0 + x
+            if not 0 <= gx < X:
+                continue
+            for y in range(ry):
+                gy = y0 + y
+                if not 0 <= gy < Y:
+                    continue
+                zlo, zhi = max(0, -z0), min(rz, Z - z0)
+                if zhi > zlo:
+                    wn = w[x, y, zlo:zhi] * ic[gx, gy, z0 + zlo:z0 + zhi]
+                    o[gx, gy, z0 + zlo:z0 + zhi, :C] += wn[:, None] * l[x, y, zlo:zhi, :C]
+
 
 def patch_native(nat, emu):
     """route capstone_amd._native.call (direct engine calls) through the emulator; returns an undo callable"""

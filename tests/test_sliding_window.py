@@ -1,0 +1,120 @@
+"""Sliding-window inference: product vs the MONAI-0.3 restatement in oracle/sliding_window.py.
+
+CPU: window grid + importance maps (host logic) and the whole inferer through the numpy ABI emulator.
+GPU (-m gpu): the same comparison through the HIP kernels, fp32 and bf16, and the SlidingWindowInferer surface."""
+import numpy as np
+import pytest
+import torch
+
+from capstone_amd import _native as nat
+from capstone_amd import inferers, plan as plan_mod
+from capstone_amd.models import UNet
+from oracle import sliding_window as OS
+from oracle.monai_unet import UNet as OracleUNet
+
+
+def _pair(dims=3, chans=(4, 8, 16), strides=(2, 2), nres=2, precision="fp32", seed=3):
+    torch.manual_seed(seed)
+    ref = OracleUNet(dims, 1, 10, chans, strides, num_res_units=nres)
+    net = UNet(dims, 1, 10, chans, strides, num_res_units=nres, precision=precision)
+    net.load_state_dict(ref.state_dict())
+    return ref.eval(), net
+
+
+@pytest.mark.parametrize("img,roi,overlap", [((40, 36, 24), (32, 32, 16), 0.25), ((512, 512, 160), (192, 192, 64), 0.25),
+                                             ((20, 64, 9), (32, 32, 16), 0.5), ((33, 17, 8), (16, 16, 8), 0.0),
+                                             ((64, 64, 1), (32, 48, 1), 0.6)])
+def test_window_grid_matches_monai_restatement(img, roi, overlap):
+    padded = tuple(max(i, r) for i, r in zip(img, roi))
+    mine = inferers._window_starts(padded, roi, inferers._scan_interval(padded, roi, overlap))
+    ref = OS.dense_patch_slices(padded, roi, OS.get_scan_interval(padded, roi, overlap))
+    assert mine == [tuple(s.start for s in sl) for sl in ref]
+    assert all(sl[d].stop - sl[d].start == roi[d] for sl in ref for d in range(3))
+
+
+@pytest.mark.parametrize("roi", [(32, 32, 16), (192, 192, 64), (16, 8, 4), (7, 9, 5)])
+def test_gaussian_importance_closed_form_equals_filtered_impulse(roi):
+    ref = OS.compute_importance_map(roi, "gaussian").numpy()
+    mine = inferers._importance_map(roi, "gaussian", 0.125)
+    np.testing.assert_allclose(mine, ref, rtol=1e-5, atol=1e-9)
+    assert mine.min() > 0 and mine.max() == 1.0
+    assert (inferers._importance_map(roi, "constant", 0.125) == 1).all()
+
+
+@pytest.fixture()
+def emu():
+    from abi_emulator import Emulator, patch_native
+    e = Emulator()
+    undo = patch_native(nat, e)
+    orig = plan_mod.Plan.run
+    plan_mod.Plan.run = staticmethod(lambda prog, stream, lo=0, hi=None: e.run(prog[lo:hi]))
+    yield e
+    plan_mod.Plan.run = orig
+    undo()
+
+
+@pytest.mark.parametrize("mode,img,roi,swb", [("constant", (20, 12, 8), (8, 8, 4), 3), ("gaussian", (12, 20, 8), (8, 8, 8), 2),
+                                              ("gaussian", (6, 12, 4), (8, 8, 4), 4)])
+def test_inferer_host_logic_emulated(emu, mode, img, roi, swb):
+    ref, net = _pair(chans=(4, 8), strides=(2,))
+    x = torch.randn(1, 1, *img)
+    with torch.no_grad():
+        want = OS.sliding_window_inference(x, roi, swb, ref, 0.25, mode)
+    got = inferers.sliding_window_inference(x, roi, swb, net, 0.25, mode)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    plan = net.engine().last_plan
+    assert plan.inference and not plan.bwd
+    with pytest.raises(RuntimeError):
+        plan.backward()
+
+
+def test_inferer_rejects_what_it_cannot_run(emu):
+    _, net = _pair(chans=(4, 8), strides=(2,))
+    with pytest.raises(NotImplementedError):
+        inferers.sliding_window_inference(torch.zeros(2, 1, 8, 8, 4), (8, 8, 4), 1, net)
+    with pytest.raises(TypeError):
+        inferers.sliding_window_inference(torch.zeros(1, 1, 8, 8, 4), (8, 8, 4), 1, lambda t: t)
+    with pytest.raises(ValueError):
+        inferers.sliding_window_inference(torch.zeros(1, 1, 8, 8, 4), (7, 8, 4), 1, net)    # ROI not divisible by 2
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,img,roi,swb,precision", [
+    ("constant", (40, 36, 24), (32, 32, 16), 3, "fp32"),
+    ("gaussian", (40, 36, 24), (32, 32, 16), 2, "fp32"),
+    ("gaussian", (24, 48, 12), (32, 32, 16), 4, "fp32"),          # first/last axis smaller than the ROI: padded + cropped
+    ("gaussian", (40, 36, 24), (32, 32, 16), 2, "bf16"),
+])
+def test_sliding_window_gpu_vs_oracle(mode, img, roi, swb, precision):
+    ref, net = _pair(chans=(8, 16, 32), strides=(2, 2), precision=precision)
+    net = net.cuda()
+    x = torch.randn(1, 1, *img)
+    with torch.no_grad():
+        want = OS.sliding_window_inference(x, roi, swb, ref, 0.25, mode)
+    got = inferers.SlidingWindowInferer(roi, swb, 0.25, mode)(x.cuda(), net).cpu()
+    assert got.shape == want.shape
+    if precision == "fp32":
+        assert (got - want).abs().max() < 1e-3          # north_star's fp32 logit tolerance
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
+        agree = (got.argmax(1) == want.argmax(1)).float().mean().item()
+        assert agree > 0.9999
+    else:
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        assert err < 4e-2
+        assert (got.argmax(1) == want.argmax(1)).float().mean().item() > 0.97
+
+
+@pytest.mark.gpu
+def test_sliding_window_2d_and_plan_reuse():
+    ref, net = _pair(dims=2, chans=(8, 16), strides=(2,))
+    net = net.cuda()
+    x = torch.randn(1, 1, 40, 28)
+    with torch.no_grad():
+        want = OS.sliding_window_inference(x, (16, 16), 4, ref, 0.5, "gaussian")
+    got = inferers.sliding_window_inference(x.cuda(), (16, 16), 4, net, 0.5, "gaussian")
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
+    n_plans = len(net.engine().plans)
+    inferers.sliding_window_inference(x.cuda(), (16, 16), 4, net, 0.5, "constant")
+    assert len(net.engine().plans) == n_plans           # the inference plan is cached per (batch, ROI)

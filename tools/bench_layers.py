@@ -59,14 +59,22 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--loop", type=int, default=20)
     ap.add_argument("--min-ms", type=float, default=0.03)
+    ap.add_argument("--filters", type=int, nargs="+", default=list(FILTERS))
+    ap.add_argument("--infer", action="store_true", help="inference-only plan (forward program of a sliding-window batch)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(SEED)
-    m = BaseUNet3D(filters=list(FILTERS), loss_fx=["CrossEntropy"], precision=a.precision).to(dev)
-    batch = synthetic_batch(*a.shape, dev, SEED)
-    m.fit_step(batch)
-    m.fit_step(batch)
-    plan = m.unet.engine().last_plan
+    m = BaseUNet3D(filters=a.filters, loss_fx=["CrossEntropy"], precision=a.precision).to(dev)
+    if a.infer:
+        plan = m.unet.engine().plan_for_shape(dev, a.shape[0], a.shape[1:], inference=True)
+        plan.x.t.normal_()
+        plan.forward()
+        plan.forward()
+    else:
+        batch = synthetic_batch(*a.shape, dev, SEED)
+        m.fit_step(batch)
+        m.fit_step(batch)
+        plan = m.unet.engine().last_plan
     st = nat.stream_ptr()
     progs = {"fwd": plan.fwd, "bwd": plan.bwd}
     if a.only:
