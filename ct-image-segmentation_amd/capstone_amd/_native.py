@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libctseg_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, I16, U8 = 0, 1, 2, 3
 MAX_TAPS, MAX_CLASSES = 27, 8
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
 _EPC = {F32: 4, BF16: 8}
@@ -90,6 +90,7 @@ _SIGS = {
     "ctseg_cast": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp]),
     "ctseg_nc_to_cl": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     "ctseg_cl_to_nc": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
+    "ctseg_resize3d_to_hwd": (C.c_int, [_vp, _i32, _vp] + [_i32] * 8 + [_f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ctseg_window_gather": (C.c_int, [_vp] + [_i32] * 10 + [_f32, _vp, _i32, _i32, _vp]),
     "ctseg_window_blend": (C.c_int, [_vp] + [_i32] * 8 + [_vp, _vp, _vp] + [_i32] * 4 + [_vp]),
 }

@@ -42,6 +42,10 @@ def cl_logits(t):
 def squash_masks(masks, n_classes=N_CLASSES, want_i64=True):
     """_squash_masks_3D / _squash_masks on device: (B,K,*sp) uint8 -> labels u8 (B,S), int64 (B,*sp), hist (B,K+1)."""
     nat.require_gpu(masks, "_squash_masks")
+    pre = getattr(masks, "_ctseg_labels", None)
+    if pre is not None and masks.dtype == torch.uint8:
+        # label maps squashed by the device input pipeline (volumetric/datasets.collate_3d): nothing left to do
+        return pre[0], (masks.long() if want_i64 else None), pre[1]
     if masks.dtype != torch.uint8:
         masks = masks.to(torch.uint8)
     masks = masks.contiguous()

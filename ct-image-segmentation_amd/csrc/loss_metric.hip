@@ -272,6 +272,83 @@ extern "C" int ctseg_squash_masks(const uint8_t* masks, int32_t B, int32_t K, in
   return 0;
 }
 
+
+// ---- 3-D input pipeline: nearest Resize3D + (D,H,W)->(H,W,D) + optional window + optional squash ----
+// One workgroup = one h, a 64-wide w tile and a 32-deep d tile.  Phase 1 reads the source along w (its contiguous axis), phase 2
+// writes the target along d (its contiguous axis); the transposition goes through LDS.  Index rule = torch's nearest:
+// src = min((int)floorf(dst * ((float)in / out)), in - 1).
+constexpr int RZ_TW = 64, RZ_TD = 32, RZ_KMAX = 15;
+__device__ __forceinline__ int rz_src(int dst, float scale, int in) {
+  const int s = (int)floorf((float)dst * scale);
+  return s < in - 1 ? s : in - 1;
+}
+template <typename TI>
+__global__ __launch_bounds__(256) void resize3d_hwd_kernel(const TI* __restrict__ image, const uint8_t* __restrict__ masks, int K, int D, int H,
+                                                           int W, int Do, int Ho, int Wo, float sD, float sH, float sW, int window,
+                                                           float win_lo, float win_hi, float* __restrict__ image_out,
+                                                           uint8_t* __restrict__ masks_out, uint8_t* __restrict__ labels_out,
+                                                           unsigned long long* __restrict__ hist) {
+  __shared__ float s_img[RZ_TD][RZ_TW + 1];
+  __shared__ uint8_t s_lab[RZ_TD][RZ_TW + 4];
+  __shared__ unsigned short s_bits[RZ_TD][RZ_TW + 2];      // bit k = mask k at this voxel (masks_out only)
+  __shared__ unsigned int s_h[RZ_KMAX + 1];
+  const int t = threadIdx.x;
+  const int ndt = (Do + RZ_TD - 1) / RZ_TD;
+  const int d0 = (blockIdx.x % ndt) * RZ_TD, w0 = (blockIdx.x / ndt) * RZ_TW, h = blockIdx.y;
+  if (t <= RZ_KMAX) s_h[t] = 0;
+  __syncthreads();
+  const int sh = rz_src(h, sH, H);
+  {
+    const int ww = t & 63, w = w0 + ww;
+    const int sw = rz_src(w < Wo ? w : Wo - 1, sW, W);
+    for (int r = 0; r < RZ_TD / 4; ++r) {
+      const int dd = r * 4 + (t >> 6), d = d0 + dd;
+      if (w >= Wo || d >= Do) continue;
+      const int64_t src = ((int64_t)rz_src(d, sD, D) * H + sh) * W + sw;
+      if (image) {
+        float v = (float)image[src];
+        if (window) {
+          v = fminf(fmaxf(v, win_lo), win_hi);
+          if (window == 2) v = (v - win_lo) / (float)((double)win_hi - (double)win_lo + 1e-8);   // numpy float32 arithmetic of apply_window
+        }
+        s_img[dd][ww] = v;
+      }
+      if (masks) {
+        int lab = 0;
+        unsigned bits = 0;
+        for (int k = 0; k < K; ++k) {
+          const int m = masks[(int64_t)k * D * H * W + src];
+          bits |= (m ? 1u : 0u) << k;
+          const int val = m * (k + 1);
+          lab = val > lab ? val : lab;
+        }
+        s_lab[dd][ww] = (uint8_t)lab;
+        s_bits[dd][ww] = (unsigned short)bits;
+        if (hist) atomicAdd(&s_h[lab & RZ_KMAX], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int dd = t & 31, d = d0 + dd;
+    for (int r = 0; r < RZ_TW / 8; ++r) {
+      const int ww = r * 8 + (t >> 5), w = w0 + ww;
+      if (w >= Wo || d >= Do) continue;
+      const int64_t dst = ((int64_t)h * Wo + w) * Do + d;
+      if (image) image_out[dst] = s_img[dd][ww];
+      if (masks) {
+        if (labels_out) labels_out[dst] = s_lab[dd][ww];
+        if (masks_out) {
+          const unsigned bits = s_bits[dd][ww];
+          for (int k = 0; k < K; ++k) masks_out[(int64_t)k * Ho * Wo * Do + dst] = (uint8_t)((bits >> k) & 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (hist && t <= K && s_h[t]) atomicAdd(&hist[t], (unsigned long long)s_h[t]);
+}
+
 extern "C" int ctseg_seg_loss(const float* logits, int32_t ld, const uint8_t* labels, int32_t B, int64_t S, int32_t C,
                               const float* class_weight, int32_t do_stats, double* part, int32_t P, int64_t* cnt,
                               int32_t do_grad, const float* coef, void* dlogits, int32_t g_ld, int32_t gdtype, uint8_t* pred_out,
@@ -312,5 +389,28 @@ extern "C" int ctseg_dice_counts(const uint8_t* pred, const uint8_t* truth, int3
   hipLaunchKernelGGL(dice_counts_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, pred, truth, S, C,
                      (unsigned long long*)cnt);
   CTSEG_LAUNCH_CHECK("dice_counts");
+  return 0;
+}
+
+extern "C" int ctseg_resize3d_to_hwd(const void* image, int32_t image_dtype, const uint8_t* masks, int32_t K, int32_t D, int32_t H,
+                                     int32_t W, int32_t Do, int32_t Ho, int32_t Wo, int32_t window, float win_lo, float win_hi,
+                                     float* image_out, uint8_t* masks_out, uint8_t* labels_out, int64_t* hist, void* stream) {
+  CTSEG_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0 && (image || masks), "resize3d_to_hwd: bad geometry");
+  CTSEG_REQUIRE(!image || image_out, "resize3d_to_hwd: image without image_out");
+  CTSEG_REQUIRE(!masks || (K > 0 && K <= RZ_KMAX && (masks_out || labels_out)), "resize3d_to_hwd: masks need K <= 15 and an output");
+  CTSEG_REQUIRE(!hist || labels_out, "resize3d_to_hwd: hist needs labels_out");
+  CTSEG_REQUIRE(window >= 0 && window <= 2 && (!window || win_hi > win_lo), "resize3d_to_hwd: bad window");
+  CTSEG_REQUIRE(image_dtype == CTSEG_F32 || image_dtype == CTSEG_I16 || image_dtype == CTSEG_U8, "resize3d_to_hwd: image dtype %d", image_dtype);
+  const float sD = (float)D / (float)Do, sH = (float)H / (float)Ho, sW = (float)W / (float)Wo;
+  dim3 grid(((Do + RZ_TD - 1) / RZ_TD) * ((Wo + RZ_TW - 1) / RZ_TW), Ho);
+  hipStream_t st = (hipStream_t)stream;
+#define CTSEG_RZ_LAUNCH(TI)                                                                                                         \
+  hipLaunchKernelGGL(resize3d_hwd_kernel<TI>, grid, dim3(256), 0, st, (const TI*)image, masks, K, D, H, W, Do, Ho, Wo, sD, sH, sW, window, \
+                     win_lo, win_hi, image_out, masks_out, labels_out, (unsigned long long*)hist)
+  if (image_dtype == CTSEG_F32) CTSEG_RZ_LAUNCH(float);
+  else if (image_dtype == CTSEG_I16) CTSEG_RZ_LAUNCH(short);
+  else CTSEG_RZ_LAUNCH(uint8_t);
+#undef CTSEG_RZ_LAUNCH
+  CTSEG_LAUNCH_CHECK("resize3d_to_hwd");
   return 0;
 }

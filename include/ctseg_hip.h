@@ -26,6 +26,8 @@ extern "C" {
 #define CTSEG_ABI_VERSION 1
 #define CTSEG_F32 0
 #define CTSEG_BF16 1
+#define CTSEG_I16 2 /* raw-input dtypes of ctseg_resize3d_to_hwd only */
+#define CTSEG_U8 3
 #define CTSEG_MAX_TAPS 27
 #define CTSEG_MAX_CLASSES 8
 
@@ -162,6 +164,19 @@ int ctseg_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype,
 /* fp32 [N][C][S] (torch NC*) -> dtype [N][S][ld] channels-last (pad channels zeroed) and back (fp32 out) */
 int ctseg_nc_to_cl(const float* src, void* dst, int32_t dtype, int32_t N, int32_t C, int64_t S, int32_t ld, void* stream);
 int ctseg_cl_to_nc(const void* src, int32_t dtype, float* dst, int32_t N, int32_t C, int64_t S, int32_t ld, void* stream);
+
+/* 3-D input pipeline on the device: one pass per instance replaces
+ *   Resize3D.apply / apply_to_mask   capstone/volumetric/transforms.py:14-22  (F.interpolate, mode "nearest":
+ *                                    src = min((int)floorf(dst * ((float)in / out)), in - 1) per axis)
+ *   ToTensorV3.apply / apply_to_mask capstone/volumetric/transforms.py:39-43  ((C,D,H,W) -> (C,H,W,D))
+ *   optionally _squash_masks_3D      capstone/volumetric/utils.py:4-7         (labels_out, + per-class voxel counts in hist[K+1],
+ *                                    which the caller zeroes) and the HU window of capstone/transforms/transforms_2d.py:97-107
+ *                                    (window 0: none, 1: clip to [lo,hi], 2: clip and map to [0,1]; the 3-D reference path has none).
+ * image [D][H][W] of image_dtype (CTSEG_F32 / CTSEG_I16 / CTSEG_U8) -> image_out fp32 [Ho][Wo][Do];
+ * masks [K][D][H][W] u8 -> masks_out [K][Ho][Wo][Do] and/or labels_out [Ho][Wo][Do].  image or masks may be NULL. */
+int ctseg_resize3d_to_hwd(const void* image, int32_t image_dtype, const uint8_t* masks, int32_t K, int32_t D, int32_t H, int32_t W,
+                          int32_t Do, int32_t Ho, int32_t Wo, int32_t window, float win_lo, float win_hi, float* image_out,
+                          uint8_t* masks_out, uint8_t* labels_out, int64_t* hist, void* stream);
 
 /* Sliding-window inference (BASELINE.json configs[4]).  The reference has no inferer (grep: 0 hits); the
  * semantics are those of MONAI 0.3 `monai.inferers.sliding_window_inference`, the companion of the `monai.networks.nets.UNet`

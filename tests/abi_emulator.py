@@ -273,6 +273,33 @@ class Emulator:
         s = mem(src, N * S * ld).reshape(N, S, ld)
         mem(dst, N * C * S).reshape(N, C, S)[:] = np.transpose(s[..., :C], (0, 2, 1))
 
+    def resize3d_to_hwd(self, image, image_dtype, masks, K, D, H, W, Do, Ho, Wo, window, lo, hi, image_out, masks_out, labels_out, hist):
+        def idx(o, i):
+            sc = np.float32(i) / np.float32(o)
+            return np.minimum(np.floor(np.arange(o, dtype=np.float32) * sc).astype(np.int64), i - 1)
+        iD, iH, iW = idx(Do, D), idx(Ho, H), idx(Wo, W)
+
+        def pick(vol):          # (D,H,W) -> (Ho,Wo,Do)
+            return np.transpose(vol[iD][:, iH][:, :, iW], (1, 2, 0))
+        if image:
+            dt = {0: np.float32, 2: np.int16, 3: np.uint8}[image_dtype]
+            v = pick(mem(image, D * H * W, dt).reshape(D, H, W)).astype(np.float32)
+            if window:
+                v = np.clip(v, np.float32(lo), np.float32(hi))
+                if window == 2:
+                    v = (v - np.float32(lo)) / np.float32(float(hi) - float(lo) + 1e-8)
+            mem(image_out, Ho * Wo * Do).reshape(Ho, Wo, Do)[:] = v
+        if masks:
+            m = mem(masks, K * D * H * W, np.uint8).reshape(K, D, H, W)
+            r = np.stack([pick(m[k]) for k in range(K)])
+            if masks_out:
+                mem(masks_out, K * Ho * Wo * Do, np.uint8).reshape(K, Ho, Wo, Do)[:] = (r != 0)
+            if labels_out:
+                lab = (r.astype(np.int32) * np.arange(1, K + 1).reshape(K, 1, 1, 1)).max(0)
+                mem(labels_out, Ho * Wo * Do, np.uint8).reshape(Ho, Wo, Do)[:] = lab
+                if hist:
+                    mem(hist, K + 1, np.int64)[:] += np.bincount(lab.reshape(-1), minlength=K + 1)
+
     def window_gather(self, vol, Cin, X, Y, Z, x0, y0, z0, rx, ry, rz, cval, dst, dtype, ld):
         assert dtype == F32
         v = mem(vol, Cin * X * Y * Z).reshape(Cin, X, Y, Z)

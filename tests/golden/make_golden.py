@@ -21,6 +21,10 @@ Nothing here travels to the GPU box except the .npz outputs. Three fixture famil
        Every arithmetic statement executed is the reference's.
 2. ``ops_torch.npz`` — op-level forward/backward of the torch CPU primitives MONAI composes
    (Conv3d k3 s1/s2, k1, ConvTranspose3d k3 s2 p1 op1, InstanceNorm3d, PReLU), odd sizes.
+   ``pipeline3d.npz`` — the reference's 3-D input transforms (capstone/volumetric/transforms.py ``Resize3D`` +
+   ``ToTensorV3``, the composition of volumetric/predefined.py:4-7) followed by ``_squash_masks_3D``; ``albumentations``
+   is absent, so the file is loaded with a structural ``DualTransform`` base class (stores always_apply/p, nothing
+   else): every statement executed in apply/apply_to_mask is the reference's.
 3. ``unet_tiny.npz`` — end-to-end tiny 3-D U-Net step from the oracle restatement
    (weights stored in the fixture, so no RNG-order parity is needed on the GPU box).
    MONAI's UNet cannot be executed here => these vectors pin the build to the ORACLE,
@@ -185,6 +189,38 @@ def ref_leaf():
     print("ref_leaf.npz:", len(out), "arrays")
 
 
+def pipeline3d():
+    class DualTransform:      # structural stand-in for albumentations' base class: no arithmetic
+        def __init__(self, always_apply=False, p=0.5):
+            self.always_apply, self.p = always_apply, p
+
+    for name in ("albumentations", "albumentations.core"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    ti = types.ModuleType("albumentations.core.transforms_interface")
+    ti.DualTransform = DualTransform
+    sys.modules[ti.__name__] = ti
+    tr = _load("ref_vol_transforms", "capstone/volumetric/transforms.py")
+    vu = _load("ref_vol_utils2", "capstone/volumetric/utils.py")
+    g = torch.Generator().manual_seed(SEED + 7)
+    out = {}
+    cases = {"up": ((5, 12, 10), (8, 16, 24)), "down": ((23, 37, 41), (8, 16, 16)), "mixed": ((9, 20, 33), (16, 8, 40)),
+             "same": ((8, 16, 8), (8, 16, 8))}
+    for tag, ((D, H, W), size) in cases.items():
+        image = (torch.randn(1, D, H, W, generator=g) * 300).numpy().astype(np.float32)
+        masks = (torch.rand(9, D, H, W, generator=g) < 0.2).to(torch.uint8).numpy()
+        rz, tt = tr.Resize3D(size=size), tr.ToTensorV3()
+        img_out = tt.apply(rz.apply(image))                                    # (1,H',W',D')
+        m_out = torch.stack([tt.apply_to_mask(rz.apply_to_mask(m)) for m in masks])   # (9,H',W',D')
+        lab = vu._squash_masks_3D(m_out.unsqueeze(0), 10, "cpu")[0]
+        out[f"{tag}_size"] = np.array(size)
+        out[f"{tag}_image"], out[f"{tag}_masks"] = image, masks
+        out[f"{tag}_image_out"], out[f"{tag}_masks_out"], out[f"{tag}_labels"] = img_out.numpy(), m_out.numpy(), lab.numpy()
+    np.savez_compressed(os.path.join(HERE, "pipeline3d.npz"), **out)
+    print("pipeline3d.npz:", len(out), "arrays")
+
+
 def ops_torch():
     g = torch.Generator().manual_seed(SEED + 1)
     out = {}
@@ -261,6 +297,6 @@ def unet_tiny():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["ref_leaf", "ops_torch", "unet_tiny"]
+    which = sys.argv[1:] or ["ref_leaf", "pipeline3d", "ops_torch", "unet_tiny"]
     for w in which:
         globals()[w]()
