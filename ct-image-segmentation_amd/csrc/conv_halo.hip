@@ -40,7 +40,9 @@ template <int VB, int NT> struct HaloCfg {
   static constexpr int TOTAL = WBYTES + 2 * HALO + 4 * 2 * BN * 4 + 32 * 4;
 };
 
-template <typename T, int VB, int NT, bool STATS>
+// ADDC: the addend IS the input tensor (identity residual: out = conv(x) + x, and its gradient) — taken from the centre
+// voxel of the LDS halo instead of a second trip to HBM.
+template <typename T, int VB, int NT, bool STATS, bool ADDC>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int total_tiles, int tyn, int tzn) {
   constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
   using CF = HaloCfg<VB, NT>;
@@ -212,7 +214,20 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
 #pragma unroll
     for (int i = 0; i < 4; ++i) rv[i] = xok && zok && (y0 + 2 * i + pdy < P.Yr);
     u32x4 av[NT][4];
-    if (P.add != nullptr) {
+    if constexpr (ADDC) {
+      const char* hc = sH + buf * CF::HALO;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int cb = (j * 16 + 4 * q4) * SZ;          // byte offset of the lane's 4 channels inside the voxel
+          const char* ap = hc + (cb >> 4) * H_PLANE + abase[i] + (cb & 15);
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (SZ == 4) v = *reinterpret_cast<const u32x4*>(ap);
+          else { const u32x2 w2 = *reinterpret_cast<const u32x2*>(ap); v[0] = w2[0]; v[1] = w2[1]; }
+          av[j][i] = v;
+        }
+    } else if (P.add != nullptr) {
       const char* ab = P.add + vb * P.add_ld * ASZ;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -337,8 +352,13 @@ template <typename T, int VB, int NT> static void launch_halo(ConvKArgs& a, hipS
   const int total = a.tiles * a.N;
   const int gx = halo_grid<VB, NT>(total);
   dim3 grid((unsigned)gx, (unsigned)((a.Cn + 16 * NT - 1) / (16 * NT)), 1);
-  if (a.stats != nullptr) hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, true>), grid, dim3(256), 0, st, a, total, tyn, tzn);
-  else hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, false>), grid, dim3(256), 0, st, a, total, tyn, tzn);
+  constexpr int SZ = TT<T>::SZ;
+  // identity residual: same tensor, same storage type, every stored channel present in the staged voxel, single column block
+  const bool addc = a.add == a.in && a.add_ld == a.g_ld && (a.add_f32 != 0) == (SZ == 4) && a.Cn_store * SZ <= VB && grid.y == 1 &&
+                    a.stats == nullptr;
+  if (a.stats != nullptr) hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, true, false>), grid, dim3(256), 0, st, a, total, tyn, tzn);
+  else if (addc) hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, false, true>), grid, dim3(256), 0, st, a, total, tyn, tzn);
+  else hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, false, false>), grid, dim3(256), 0, st, a, total, tyn, tzn);
 }
 
 void launch_conv_halo(ConvKArgs& a, int dtype, hipStream_t st) {
