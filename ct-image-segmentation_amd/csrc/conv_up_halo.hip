@@ -10,6 +10,7 @@
 // (same 6x10x10 slot geometry, so every ds_read_b128 operand fetch is bank-conflict free); InstanceNorm partial sums
 // are accumulated over the 8 classes in registers -> one partial slot per tile.
 #include "conv_common.h"
+#include <type_traits>
 
 namespace ctseg {
 
@@ -25,22 +26,23 @@ template <int VB> struct UpCfg {
   static constexpr int NPL = VB / 16;
   static constexpr int HALO = NPL * U_PLANE;
   static constexpr int WBYTES = 27 * (VB / 64) * 16 * 64;   // 27 taps x (VB/64) 64-byte chunks x 16 rows  (= 27*Cg*16*2)
-  static constexpr int TOTAL = WBYTES + 2048 + HALO + 4 * 2 * 16 * 4 + 64 * 4 + 16 * 4;
+  static constexpr int TOTAL = WBYTES + 2048 + HALO + 8 * 2 * 16 * 4 + 64 * 4 + 16 * 4;
 };
 
 template <int VB>
-__global__ __launch_bounds__(256) void conv_up_halo_kernel(const ConvKArgs P, int total_tiles, int tyn, int tzn) {
+__global__ __launch_bounds__(512) void conv_up_halo_kernel(const ConvKArgs P, int total_tiles, int tyn, int tzn) {
   using CF = UpCfg<VB>;
   constexpr int NPL = CF::NPL, CPT = VB / 64;           // 64-byte K chunks per tap
-  constexpr int NCH = U_FV * NPL, J = (NCH + 255) / 256;
+  constexpr int NTHR = 512;      // 8 waves: waves 0-3 / 4-7 split the 8 parity classes (13 / 14 taps) over the same 4x8x8 tile
+  constexpr int NCH = U_FV * NPL, J = (NCH + NTHR - 1) / NTHR;
   __shared__ __attribute__((aligned(16))) char smem[CF::TOTAL];
   char* const sW = smem;                                 // per class: [stages][16 rows][128 B] swizzled, stage padded
   char* const sH = smem + CF::WBYTES + 2048;
   float* const sStats = reinterpret_cast<float*>(sH + CF::HALO);
-  int* const sDelta = reinterpret_cast<int*>(sH + CF::HALO + 4 * 2 * 16 * 4);   // [8 classes][8 taps]
+  int* const sDelta = reinterpret_cast<int*>(sH + CF::HALO + 8 * 2 * 16 * 4);   // [8 classes][8 taps]
   int* const sWst = sDelta + 64;                                                  // first weight stage of each class
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, wave = wave8 & 3, half = wave8 >> 2;
   const int r16 = lane & 15, q4 = lane >> 4;
 
   // ---- weights of all classes -> LDS; class c starts at stage wstage[c] ------------------------------------------------
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void conv_up_halo_kernel(const ConvKArgs P, in
   for (int c = 0; c < 8; ++c) wstage[c + 1] = wstage[c] + P.cls[c].kpad * 2 / 128;
   for (int c = 0; c < 8; ++c) {
     const int nst = wstage[c + 1] - wstage[c];
-    for (int idx = tid; idx < 16 * nst * 8; idx += 256) {
+    for (int idx = tid; idx < 16 * nst * 8; idx += NTHR) {
       const int q8 = idx & 7, row = (idx >> 3) & 15, s = idx >> 7;
       const u32x4 v = *reinterpret_cast<const u32x4*>(P.w + (P.cls[c].w_off + (int64_t)row * P.cls[c].kpad) * 2 + s * 128 + q8 * 16);
       *reinterpret_cast<u32x4*>(sW + ((wstage[c] + s) * 16 + row) * 128 + ((q8 ^ ((row >> 1) & 7)) << 4)) = v;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_up_halo_kernel(const ConvKArgs P, in
   int g_byte[J], g_hxyz[J], g_lds[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    const int idx = tid + j * 256;
+    const int idx = tid + j * NTHR;
     const int pl = (idx >> 3) % NPL, fv = (idx / (8 * NPL)) * 8 + (idx & 7);
     const int fx = fv / 81, rem = fv - fx * 81, fy = rem / 9, fz = rem - fy * 9;     // offsets 0..4, 0..8, 0..8
     g_byte[j] = ((fx * YZ + fy * P.Zi + fz) * P.g_ld + pl * 8) * 2;
@@ -131,16 +133,18 @@ __global__ __launch_bounds__(256) void conv_up_halo_kernel(const ConvKArgs P, in
 #pragma unroll
     for (int i = 0; i < 4; ++i) rv[i] = xok && zok && (y0 + 2 * i + pdy < P.Yr);
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int c = 0; c < 8; ++c) {
+    // one parity class, tap count known at compile time (class c has 2^popcount(c) taps — checked by conv_up_eligible): the
+    // fully unrolled body lets the scheduler run the LDS operand reads of the next taps under the MFMAs of the current one,
+    // which matters here because the 134 KB LDS image leaves a single wave per SIMD
+    auto do_class = [&](auto ntaps_c, const int c) {
+      constexpr int NTP = decltype(ntaps_c)::value;
       const ctseg_conv_class& K = P.cls[c];
       f32x4 acc[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       const char* wc = sW + sWst[c] * (16 * 128) + wrow;
-      const int nt = K.ntaps;
-#pragma unroll 1
-      for (int tp = 0; tp < nt; ++tp) {
+#pragma unroll
+      for (int tp = 0; tp < NTP; ++tp) {
         const int delta = sDelta[c * 8 + tp];
 #pragma unroll
         for (int kc = 0; kc < CPT; ++kc) {
@@ -177,6 +181,18 @@ __global__ __launch_bounds__(256) void conv_up_halo_kernel(const ConvKArgs P, in
           *reinterpret_cast<u32x2*>(ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
         }
       }
+    };
+    using std::integral_constant;
+    if (half == 0) {
+      do_class(integral_constant<int, 8>{}, 7);
+      do_class(integral_constant<int, 1>{}, 0);
+      do_class(integral_constant<int, 2>{}, 1);
+      do_class(integral_constant<int, 2>{}, 2);
+    } else {
+      do_class(integral_constant<int, 4>{}, 3);
+      do_class(integral_constant<int, 4>{}, 5);
+      do_class(integral_constant<int, 4>{}, 6);
+      do_class(integral_constant<int, 2>{}, 4);
     }
     if (P.stats != nullptr) {
 #pragma unroll
@@ -185,15 +201,16 @@ __global__ __launch_bounds__(256) void conv_up_halo_kernel(const ConvKArgs P, in
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
         if (r16 == 0) {
-          sStats[(wave * 2 + 0) * 16 + 4 * q4 + e] = a;
-          sStats[(wave * 2 + 1) * 16 + 4 * q4 + e] = b;
+          sStats[(wave8 * 2 + 0) * 16 + 4 * q4 + e] = a;
+          sStats[(wave8 * 2 + 1) * 16 + 4 * q4 + e] = b;
         }
       }
       __syncthreads();
       if (tid < 32) {
         const int which = tid >> 4, c = tid & 15;
-        const float a = sStats[(0 * 2 + which) * 16 + c] + sStats[(1 * 2 + which) * 16 + c] + sStats[(2 * 2 + which) * 16 + c] +
-                        sStats[(3 * 2 + which) * 16 + c];
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) a += sStats[(w * 2 + which) * 16 + c];
         const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + (t - n * tiles_per_sample);
         P.stats[(slot_t * 2 + which) * P.stats_ld + c] = a;
       }
@@ -238,7 +255,7 @@ bool conv_up_eligible(const ConvKArgs& a, int dtype, int nclass) {
   int taps = 0;
   for (int c = 0; c < 8; ++c) {
     const ctseg_conv_class& k = a.cls[c];
-    if (k.ntaps < 1 || k.ntaps > 8 || k.kpad != ((k.ntaps * a.Cg + 63) / 64) * 64) return false;
+    if (k.ntaps != (1 << __builtin_popcount(c)) || k.kpad != ((k.ntaps * a.Cg + 63) / 64) * 64) return false;
     taps += k.ntaps;
     for (int j = 0; j < k.ntaps; ++j)
       for (int s = 0; s < 24; s += 8) {
@@ -258,8 +275,8 @@ void launch_conv_up(ConvKArgs& a, hipStream_t st) {
   const int vb = a.Cg * 2;
   int gx = (vb == 128) ? 256 : 512;
   if (gx > total) gx = total;
-  if (vb == 128) hipLaunchKernelGGL((conv_up_halo_kernel<128>), dim3(gx), dim3(256), 0, st, a, total, tyn, tzn);
-  else hipLaunchKernelGGL((conv_up_halo_kernel<64>), dim3(gx), dim3(256), 0, st, a, total, tyn, tzn);
+  if (vb == 128) hipLaunchKernelGGL((conv_up_halo_kernel<128>), dim3(gx), dim3(512), 0, st, a, total, tyn, tzn);
+  else hipLaunchKernelGGL((conv_up_halo_kernel<64>), dim3(gx), dim3(512), 0, st, a, total, tyn, tzn);
 }
 
 }  // namespace ctseg
