@@ -175,5 +175,9 @@ void launch_conv_up(ConvKArgs& a, hipStream_t st);
 bool conv_stem_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_stem_slots(const ConvKArgs& a);
 void launch_conv_stem(ConvKArgs& a, hipStream_t st);
+// conv_halo_sw.hip: LDS halo + streamed weights, Cg=64->Cn=64 (one class) and Cg=128->Cn=32 (8 parity classes), bf16
+bool conv_halo_sw_eligible(const ConvKArgs& a, int dtype, int nclass);
+int conv_halo_sw_slots(const ConvKArgs& a);
+void launch_conv_halo_sw(ConvKArgs& a, int nclass, hipStream_t st);
 
 }  // namespace ctseg

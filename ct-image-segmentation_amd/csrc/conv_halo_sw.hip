@@ -1,0 +1,394 @@
+// LDS-halo implicit-GEMM kernel with STREAMED weights for the 64- and 128-channel 3x3x3 passes (gfx950, bf16):
+//   * Conv3d 64 -> 64 k3 s1 forward / input gradient at 128x128x12            (one class, 27 taps, Cg = 64,  Cn = 64)
+//   * the 8-parity-class stride-2 passes with Cg = 128 -> Cn = 32 at 128x128x12 (ConvTranspose3d 128 -> 32 forward and the
+//     input gradient of the fused stride-2 [residual | unit0] convolution 32 -> 64+64): 1+2+2+2+4+4+4+8 = 27 taps
+// of the reference's U-Net (MONAI UNet built at capstone/volumetric/base_trainer.py:65-72).
+//
+// The generic kernel (conv_igemm.hip) re-gathers every im2col row chunk through L2 for each of its 27 taps; at these channel
+// counts it is bound by L2 -> LDS operand traffic (43 FLOP/B with the 128x64 tile, 29 FLOP/B with 256x32), not by MFMA or HBM.
+// Here one 8-wave workgroup per CU stages the input halo of a TXx8x8 tile ONCE (conv_halo.hip's plane layout and lane<->voxel
+// permutation: conflict-free ds_read_b128 for every tap) and streams the packed weights of the 27 (class, tap) pairs through a
+// two-slot LDS ring, three taps (24 KB) per stage, with direct-to-LDS loads (global_load_lds, swizzle applied on the source
+// side).  Every workgroup walks the same weight sequence, so the stream is an L2 hit; per tile the CU moves 77-102 KB of halo +
+// 221 KB of weights for 57 (28) MFLOP: >100 FLOP per operand byte.
+//
+// The tile's long axes can be mapped to any pair of volume axes (`perm`): the reference's 12-deep level would waste a third of
+// an 8-deep z tile, so there the short tile axis (4 or 2) runs along z and the 8x8 face covers (x, y).
+#include "conv_common.h"
+
+namespace ctseg {
+
+constexpr int SW_NTHR = 512, SW_G = 3, SW_NSTAGE = 9, SW_TAPB = 8192;
+
+template <int VB> struct SwCfg {
+  static constexpr int TA = VB == 128 ? 4 : 2;          // short tile axis
+  static constexpr int HV = (TA + 2) * 100;             // halo slots, (TA+2) x 10 x 10
+  static constexpr int NPL = VB / 16, PLANE = HV * 16, HALO = NPL * PLANE;
+  static constexpr int CG = VB / 2, CN = SW_TAPB / VB;  // 64 -> 64, 128 -> 32
+  static constexpr int NT = CN / 16;
+  static constexpr int RT = TA / 2;                     // row tiles (16 voxels) per wave
+  static constexpr int KS = CG / 32;                    // 32-wide k-steps per tap
+  static constexpr int WRING = 2 * SW_G * SW_TAPB;
+  static constexpr int TOTAL = HALO + WRING + 8 * 2 * CN * 4 + 128 * 4;
+};
+
+struct SwGeom {
+  int da, db, dc;            // extents of the row grid along the tile axes (a = short axis)
+  int ia, ib, ic;            // gathered-tensor voxel strides of the tile axes
+  int oa, ob, oc;            // written-tensor voxel strides of the tile axes (already multiplied by sout)
+  int pa, pb, pc;            // which volume axis (0 = x, 1 = y, 2 = z) each tile axis runs along
+  int tbn, tcn, tiles;       // tiles along b, c; tiles per sample
+};
+
+__device__ __forceinline__ void sw_patch_voxel(int r16, int& db, int& c) {
+  db = (0xEF80u >> r16) & 1;
+  c = (int)((0x2104765437653210ull >> (4 * r16)) & 7ull);
+}
+
+template <int VB, bool UP, bool STATS>
+__global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P, const SwGeom G, int total_tiles) {
+  using CF = SwCfg<VB>;
+  constexpr int TA = CF::TA, NPL = CF::NPL, PLANE = CF::PLANE, CN = CF::CN, NT = CF::NT, RT = CF::RT, KS = CF::KS;
+  constexpr int O = UP ? 1 : 0;                                        // first halo coordinate that is ever read
+  constexpr int FA = TA + 2 - O, FB = 10 - O, FV = FA * FB * FB;       // filled region of the halo image
+  constexpr int NCH = FV * NPL, J = (NCH + SW_NTHR - 1) / SW_NTHR;
+
+  __shared__ __attribute__((aligned(16))) char smem[CF::TOTAL];
+  char* const sH = smem;
+  char* const sW = smem + CF::HALO;
+  float* const sStats = reinterpret_cast<float*>(sW + CF::WRING);
+  int* const sTab = reinterpret_cast<int*>(sStats + 8 * 2 * CN);       // [0,32) halo delta, [32,64) weight offset, [64,96) kpad, [96,128) class | last<<8
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q4 = lane >> 4;
+
+  if (tid < 32) {
+    int d = 0, wo = 0, kp = 0, cl = 0;
+    if (tid < 27) {
+      int c = 0, first = 0;
+      while (tid >= first + P.cls[c].ntaps) { first += P.cls[c].ntaps; ++c; }
+      const int ti = tid - first;
+      const int tp = P.cls[c].taps[ti];
+      int dv[3] = {(int)(int8_t)(tp & 0xff), (int)(int8_t)((tp >> 8) & 0xff), (int)(int8_t)((tp >> 16) & 0xff)};
+      d = ((dv[G.pa] * 10 + dv[G.pb]) * 10 + dv[G.pc]) * 16;
+      wo = (int)(P.cls[c].w_off + (int64_t)ti * CF::CG);
+      kp = P.cls[c].kpad;
+      cl = c | ((ti == P.cls[c].ntaps - 1) ? 256 : 0);
+    }
+    sTab[tid] = d; sTab[32 + tid] = wo; sTab[64 + tid] = kp; sTab[96 + tid] = cl;
+  }
+
+  // ---- halo staging slots: per-thread constants, only a scalar tile base changes ---------------------------------------
+  int g_byte[J], g_habc[J], g_lds[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int idx = tid + j * SW_NTHR;
+    const int pl = (idx >> 3) % NPL, fv = (idx / (8 * NPL)) * 8 + (idx & 7);
+    const int fa = fv / (FB * FB), rem = fv - fa * (FB * FB), fb = rem / FB, fc = rem - fb * FB;
+    const int ha = fa + O, hb = fb + O, hc = fc + O;                   // halo coordinates, tile origin = (1,1,1)
+    g_byte[j] = (((ha - 1) * G.ia + (hb - 1) * G.ib + (hc - 1) * G.ic) * P.g_ld + pl * 8) * 2;
+    g_habc[j] = (fv < FV) ? (ha | (hb << 8) | (hc << 16)) : 0x7f7f7f;  // sentinel fails every bounds test
+    g_lds[j] = pl * PLANE + ((ha * 10 + hb) * 10 + hc) * 16;
+  }
+  const int per_sample_in = G.da * G.ia;   // not used for addressing (strides carry it); kept for clarity
+  (void)per_sample_in;
+  auto tile_origin = [&](int t, int& n, int& a0, int& b0, int& c0) {
+    n = t / G.tiles;
+    int r = t - n * G.tiles;
+    const int tc = r % G.tcn; r /= G.tcn;
+    const int tb = r % G.tbn; const int ta = r / G.tbn;
+    a0 = ta * TA; b0 = tb * 8; c0 = tc * 8;
+  };
+  const int64_t in_sample = (int64_t)P.Xi * P.Yi * P.Zi, out_sample = (int64_t)P.Xo * P.Yo * P.Zo;
+  u32x4 rh[J];
+  auto gload = [&](int t) {
+    int n, a0, b0, c0;
+    tile_origin(t, n, a0, b0, c0);
+    const char* base = P.in + (n * in_sample + (int64_t)a0 * G.ia + (int64_t)b0 * G.ib + (int64_t)c0 * G.ic) * P.g_ld * 2;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int ai = a0 - 1 + (g_habc[j] & 0xff), bi = b0 - 1 + ((g_habc[j] >> 8) & 0xff), ci = c0 - 1 + (g_habc[j] >> 16);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if ((unsigned)ai < (unsigned)G.da && (unsigned)bi < (unsigned)G.db && (unsigned)ci < (unsigned)G.dc)
+        v = *reinterpret_cast<const u32x4*>(base + g_byte[j]);
+      rh[j] = v;
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+      if ((g_habc[j] & 0xff) != 0x7f) *reinterpret_cast<u32x4*>(sH + g_lds[j]) = rh[j];
+  };
+
+  // ---- weight stream: thread = one 16-byte chunk of a tap's [CN][CG] block, lane-linear LDS image, source-side swizzle -------
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int w_s64 = tid / (CN * 8), w_row = (tid >> 3) % CN, w_q8 = (tid & 7) ^ ((w_row >> 1) & 7);
+  const int w_koff = w_s64 * 64 + w_q8 * 8;
+  int wstage = 0;                                    // running stage counter: ring slot = wstage & 1
+  auto wload = [&](int stage_in_tile, int slot) {
+    char* dst = sW + slot * (SW_G * SW_TAPB) + wave * 1024;
+#pragma unroll
+    for (int g = 0; g < SW_G; ++g) {
+      const int tap = stage_in_tile * SW_G + g;
+      const char* src = P.w + ((int64_t)sTab[32 + tap] + (int64_t)w_row * sTab[64 + tap] + w_koff) * 2;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + g * SW_TAPB), 16, 0, 0);
+    }
+  };
+
+  // ---- per-lane constants of the MFMA operands and the epilogue -------------------------------------------------------
+  int pdb, pc;
+  sw_patch_voxel(r16, pdb, pc);
+  // row tile rt of wave w: a = wa, b in {2i, 2i+1}, c 0..7 (permuted inside the 2x8 patch)
+  int abase[RT], va[RT], vb[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int wa = (TA == 4) ? (wave >> 1) : (wave >> 2);
+    const int i = (TA == 4) ? (2 * (wave & 1) + rt) : (wave & 3);
+    va[rt] = wa;
+    vb[rt] = 2 * i + pdb;
+    abase[rt] = (((wa + 1) * 10 + (vb[rt] + 1)) * 10 + (pc + 1)) * 16 + q4 * PLANE;
+  }
+  const int wrd = r16 * 128, wswz = (r16 >> 1) & 7;
+  const bool af32 = P.add_f32 != 0;
+  const int ASZ = af32 ? 4 : 2;
+  float bias[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias[j][e] = (P.bias != nullptr) ? P.bias[j * 16 + 4 * q4 + e] : 0.f;
+
+  float wsum[NT][4], wsq[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { wsum[j][e] = 0.f; wsq[j][e] = 0.f; }
+  int stat_n = -1;
+  auto flush_stats = [&](int n) {                    // called by every thread (contains barriers)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = wsum[j][e], b = wsq[j][e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (r16 == 0) {
+          const int c = j * 16 + 4 * q4 + e;
+          sStats[(wave * 2 + 0) * CN + c] = a;
+          sStats[(wave * 2 + 1) * CN + c] = b;
+        }
+        wsum[j][e] = 0.f;
+        wsq[j][e] = 0.f;
+      }
+    __syncthreads();
+    if (tid < 2 * CN) {
+      const int which = tid / CN, c = tid % CN;
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += sStats[(w * 2 + which) * CN + c];
+      const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + blockIdx.x;
+      P.stats[(slot_t * 2 + which) * P.stats_ld + c] = a;
+    }
+    __syncthreads();
+  };
+
+  f32x4 acc[RT][NT];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // epilogue of one class straight from the accumulators: lane = (voxel of row tile rt, channels j*16 + 4*q4 .. +3)
+  auto epilogue = [&](int cls, int n, int a0, int b0, int c0) {
+    const ctseg_conv_class& K = P.cls[cls];
+    int ov[3] = {K.ox, K.oy, K.oz};
+    const int64_t obase = n * out_sample + (int64_t)a0 * G.oa + (int64_t)b0 * G.ob + (int64_t)c0 * G.oc +
+                          ((int64_t)ov[0] * P.Yo + ov[1]) * P.Zo + ov[2];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool rv = (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
+      const int64_t vox = obase + (int64_t)va[rt] * G.oa + (int64_t)vb[rt] * G.ob + (int64_t)pc * G.oc;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int ch = j * 16 + 4 * q4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[rt][j][e] + bias[j][e];
+          if (STATS && rv) { wsum[j][e] += v[e]; wsq[j][e] += v[e] * v[e]; }
+        }
+        if (rv) {
+          if (P.add != nullptr) {
+            const char* ap = P.add + (vox * P.add_ld + ch) * ASZ;
+            if (af32) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap); v[0] += a4[0]; v[1] += a4[1]; v[2] += a4[2]; v[3] += a4[3]; }
+            else {
+              const u32x2 w2 = *reinterpret_cast<const u32x2*>(ap);
+              v[0] += bf2f(w2[0] & 0xffffu); v[1] += bf2f(w2[0] >> 16); v[2] += bf2f(w2[1] & 0xffffu); v[3] += bf2f(w2[1] >> 16);
+            }
+          }
+          *reinterpret_cast<u32x2*>(P.out + (vox * P.o_ld + ch) * 2) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        }
+      }
+    }
+  };
+
+  // tile sequence: each XCD owns a contiguous range of tiles (neighbouring halos share that XCD's L2)
+  const int GX = gridDim.x;
+  int first, stride, last;
+  if ((GX & 7) == 0) {
+    const int chunk = (total_tiles + 7) / 8, xcd = blockIdx.x & 7;
+    first = xcd * chunk + (blockIdx.x >> 3);
+    stride = GX >> 3;
+    last = (xcd + 1) * chunk < total_tiles ? (xcd + 1) * chunk : total_tiles;
+  } else {
+    first = blockIdx.x; stride = GX; last = total_tiles;
+  }
+
+  __syncthreads();                                   // tap tables visible
+  int t = first;
+  if (t < last) {
+    gload(t);
+    wload(0, 0);
+    sstore();
+  }
+  __syncthreads();                                   // halo + stage 0 of the weights landed
+  for (; t < last; t += stride) {
+    const int tn = t + stride;
+    int n, a0, b0, c0;
+    tile_origin(t, n, a0, b0, c0);
+    if (STATS && n != stat_n) {
+      if (stat_n >= 0) flush_stats(stat_n);
+      stat_n = n;
+    }
+    zero_acc();
+#pragma unroll 1
+    for (int s = 0; s < SW_NSTAGE; ++s) {
+      const int slot = wstage & 1;
+      if (s + 1 < SW_NSTAGE) wload(s + 1, slot ^ 1);
+      else if (tn < last) wload(0, slot ^ 1);        // first stage of the next tile
+      if (s == 0 && tn < last) gload(tn);            // next halo rides in registers until this tile is done
+      const char* wb = sW + slot * (SW_G * SW_TAPB) + wrd;
+#pragma unroll
+      for (int g = 0; g < SW_G; ++g) {
+        const int tap = s * SW_G + g;
+        const int delta = sTab[tap];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          u32x4 xf[RT], wf[NT];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) xf[rt] = *reinterpret_cast<const u32x4*>(sH + abase[rt] + ks * 4 * PLANE + delta);
+          const char* wk = wb + g * SW_TAPB + (ks >> 1) * (CN * 128) + (((4 * (ks & 1) + q4) ^ wswz) << 4);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4*>(wk + j * 16 * 128);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) mma16<BF16>(acc[rt][j], wf[j], xf[rt]);
+        }
+        if constexpr (UP) {
+          const int cl = sTab[96 + tap];
+          if (cl & 256) {                            // wave-uniform: last tap of a parity class
+            epilogue(cl & 255, n, a0, b0, c0);
+            zero_acc();
+          }
+        }
+      }
+      ++wstage;
+      __syncthreads();                               // next stage's DMA landed (vmcnt(0) before the barrier), this slot is free
+    }
+    if constexpr (!UP) epilogue(0, n, a0, b0, c0);
+    if (tn < last) {
+      // every wave passed the last stage barrier => nobody reads the halo any more
+      sstore();
+      __syncthreads();
+    }
+  }
+  if (STATS && stat_n >= 0) flush_stats(stat_n);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+static bool sw_geom(const ConvKArgs& a, int vb, SwGeom& g) {
+  const int ta = vb == 128 ? 4 : 2;
+  const int dims[3] = {a.Xr, a.Yr, a.Zr};
+  const int istr[3] = {a.Yi * a.Zi, a.Zi, 1};
+  const int ostr[3] = {a.Yo * a.Zo * a.sout, a.Zo * a.sout, a.sout};
+  auto waste = [&](int pa, int pb, int pc) {
+    const double full = (double)dims[0] * dims[1] * dims[2];
+    const double padded = (double)((dims[pa] + ta - 1) / ta * ta) * ((dims[pb] + 7) / 8 * 8) * ((dims[pc] + 7) / 8 * 8);
+    return padded / full;
+  };
+  // (a,b,c) = (x,y,z) keeps z innermost; (z,x,y) puts the short tile axis along a shallow z
+  int pa = 0, pb = 1, pc = 2;
+  if (waste(2, 0, 1) < waste(0, 1, 2) - 1e-9) { pa = 2; pb = 0; pc = 1; }
+  g.pa = pa; g.pb = pb; g.pc = pc;
+  g.da = dims[pa]; g.db = dims[pb]; g.dc = dims[pc];
+  g.ia = istr[pa]; g.ib = istr[pb]; g.ic = istr[pc];
+  g.oa = ostr[pa]; g.ob = ostr[pb]; g.oc = ostr[pc];
+  const int tan = (g.da + ta - 1) / ta;
+  g.tbn = (g.db + 7) / 8; g.tcn = (g.dc + 7) / 8;
+  g.tiles = tan * g.tbn * g.tcn;
+  return true;
+}
+
+bool conv_halo_sw_eligible(const ConvKArgs& a, int dtype, int nclass) {
+  if (dtype != CTSEG_BF16 || a.out_f32 || a.sin != 1) return false;
+  const int vb = a.Cg * 2;
+  if (!((vb == 128 && a.Cn == 64) || (vb == 256 && a.Cn == 32)) || a.Cn_store != a.Cn) return false;
+  if ((a.g_ld % 8) != 0 || ((uintptr_t)a.in % 16) != 0 || ((uintptr_t)a.w % 16) != 0) return false;
+  if (a.Xr != a.Xi || a.Yr != a.Yi || a.Zr != a.Zi) return false;
+  if ((int64_t)a.Xi * a.Yi * a.Zi * a.g_ld * 2 >= (1ll << 31)) return false;       // 32-bit per-sample byte offsets
+  if ((int64_t)a.Xr * a.Yr * a.Zr < 2048) return false;                            // too few tiles to fill the chip: generic kernel
+  const bool up = nclass == 8;
+  if (up) {
+    if (a.sout != 2 || a.Xo != 2 * a.Xr || a.Yo != 2 * a.Yr || a.Zo != 2 * a.Zr) return false;
+  } else {
+    if (nclass != 1 || a.sout != 1 || a.Xo != a.Xr || a.Yo != a.Yr || a.Zo != a.Zr) return false;
+  }
+  int taps = 0;
+  for (int c = 0; c < nclass; ++c) {
+    const ctseg_conv_class& k = a.cls[c];
+    if (up ? (k.ntaps != (1 << __builtin_popcount(c))) : (k.ntaps != 27)) return false;
+    if (k.kpad < k.ntaps * a.Cg || (k.kpad % 8) != 0 || (k.w_off % 8) != 0) return false;
+    if (k.w_off + (int64_t)a.Cn * k.kpad >= (1ll << 31)) return false;
+    taps += k.ntaps;
+    for (int j = 0; j < k.ntaps; ++j)
+      for (int s = 0; s < 24; s += 8) {
+        const int d = (int)(int8_t)((k.taps[j] >> s) & 0xff);
+        if (d < (up ? 0 : -1) || d > 1) return false;
+      }
+  }
+  return taps == 27;
+}
+
+static int sw_grid(const ConvKArgs& a, const SwGeom& g) {
+  const int total = g.tiles * a.N;
+  return total < 256 ? total : 256;
+}
+
+int conv_halo_sw_slots(const ConvKArgs& a) {
+  SwGeom g;
+  sw_geom(a, a.Cg * 2, g);
+  return sw_grid(a, g);
+}
+
+void launch_conv_halo_sw(ConvKArgs& a, int nclass, hipStream_t st) {
+  SwGeom g;
+  const int vb = a.Cg * 2;
+  sw_geom(a, vb, g);
+  a.tiles = g.tiles;
+  const int total = g.tiles * a.N;
+  const dim3 grid((unsigned)sw_grid(a, g)), blk(SW_NTHR);
+  const bool up = nclass == 8, stats = a.stats != nullptr;
+#define CTSEG_SW_LAUNCH(VB, UP, ST) hipLaunchKernelGGL((conv_halo_sw_kernel<VB, UP, ST>), grid, blk, 0, st, a, g, total)
+  if (vb == 128) {
+    if (up) { if (stats) CTSEG_SW_LAUNCH(128, true, true); else CTSEG_SW_LAUNCH(128, true, false); }
+    else { if (stats) CTSEG_SW_LAUNCH(128, false, true); else CTSEG_SW_LAUNCH(128, false, false); }
+  } else {
+    if (up) { if (stats) CTSEG_SW_LAUNCH(256, true, true); else CTSEG_SW_LAUNCH(256, true, false); }
+    else { if (stats) CTSEG_SW_LAUNCH(256, false, true); else CTSEG_SW_LAUNCH(256, false, false); }
+  }
+#undef CTSEG_SW_LAUNCH
+}
+
+}  // namespace ctseg

@@ -350,7 +350,11 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   const bool halo = conv_halo_eligible(a, d->dtype, d->nclass);
   const bool up = !halo && conv_up_eligible(a, d->dtype, d->nclass);
   const bool stem = !halo && !up && conv_stem_eligible(a, d->dtype, d->nclass);
-  if (d->stats && stem) {
+  const bool sw = !halo && !up && !stem && conv_halo_sw_eligible(a, d->dtype, d->nclass);
+  if (d->stats && sw) {
+    CTSEG_REQUIRE(d->stats_tile0 + conv_halo_sw_slots(a) <= d->stats_tiles && d->stats_ld >= d->Cn,
+                  "conv_igemm: stats partial layout (streamed-weight halo pass)");
+  } else if (d->stats && stem) {
     CTSEG_REQUIRE(d->stats_tile0 + conv_stem_slots(a) <= d->stats_tiles && d->stats_ld >= ((d->Cn + 15) / 16) * 16,
                   "conv_igemm: stats partial layout (stem pass)");
   } else if (d->stats && up) {
@@ -366,6 +370,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   if (halo) launch_conv_halo(a, d->dtype, st);
   else if (up) launch_conv_up(a, st);
   else if (stem) launch_conv_stem(a, st);
+  else if (sw) launch_conv_halo_sw(a, d->nclass, st);
   else if (d->dtype == CTSEG_F32) launch_dtype<float>(a, smallc, d->nclass, st);
   else launch_dtype<BF16>(a, smallc, d->nclass, st);
   CTSEG_LAUNCH_CHECK("conv_igemm");
@@ -373,6 +378,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
 }
 
 static void fill_args(const ctseg_conv_desc* d, ConvKArgs& a) {
+  a.w = (const char*)d->w; a.Cn_store = d->Cn_store;
   a.in = (const char*)d->in; a.N = d->N; a.Xi = d->Xi; a.Yi = d->Yi; a.Zi = d->Zi; a.Xr = d->Xr; a.Yr = d->Yr; a.Zr = d->Zr;
   a.Cg = d->Cg; a.Cn = d->Cn; a.g_ld = d->g_ld; a.sin = d->sin; a.sout = d->sout; a.rows = d->Xr * d->Yr * d->Zr;
   for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
@@ -388,6 +394,7 @@ extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
   if (conv_up_eligible(a, d->dtype, d->nclass)) return conv_up_tiles(a);
   a.add = (const char*)d->add; a.o_ld = d->o_ld;
   if (conv_stem_eligible(a, d->dtype, d->nclass)) return conv_stem_slots(a);
+  if (conv_halo_sw_eligible(a, d->dtype, d->nclass)) return conv_halo_sw_slots(a);
   const int SZq = d->dtype == CTSEG_F32 ? 4 : 2, EPCq = 16 / SZq;
   const bool smallq = (d->Cg % EPCq) != 0 || (d->g_ld % EPCq) != 0 || ((uintptr_t)d->in % 16) != 0;
   const int bm = tile_rows_for(d->Cn, d->dtype, d->out_f32, smallq);

@@ -99,6 +99,30 @@ def test_up_halo_kernel_vs_torch_cpu(kind, cin, cout, shape):
     assert rel_err(gb, mod.bias.grad) < 2.5e-2, "bias gradient"
 
 
+@pytest.mark.parametrize("kind,cin,cout,shape", [("conv", 64, 64, (2, 16, 16, 12)), ("conv", 64, 64, (1, 9, 20, 13)),
+                                                 ("conv", 64, 64, (1, 16, 16, 8)), ("convT", 128, 32, (1, 8, 16, 16)),
+                                                 ("convT", 128, 32, (2, 6, 20, 12)), ("conv_s2", 32, 128, (1, 32, 32, 16)),
+                                                 ("conv_s2", 32, 128, (1, 18, 40, 24))])
+def test_streamed_weight_halo_kernel_vs_torch_cpu(kind, cin, cout, shape):
+    """passes that take conv_halo_sw (bf16): 64->64 k3 s1 forward + input gradient (one class), ConvTranspose3d 128->32
+    forward and the input gradient of a stride-2 conv 32->128 (8 parity classes); both tile-axis mappings, ragged tiles."""
+    torch.manual_seed(cin + cout + shape[3])
+    if kind == "convT":
+        mod = torch.nn.ConvTranspose3d(cin, cout, 3, 2, 1, output_padding=1)
+    else:
+        mod = torch.nn.Conv3d(cin, cout, 3, 2 if kind == "conv_s2" else 1, 1)
+    x = torch.randn(shape[0], cin, *shape[1:])
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yy, gx, gw, gb = run_conv_module(mod, x, gy, BF16, DEV)
+    assert rel_err(yy, y.detach()) < 2.5e-2, "forward"
+    assert rel_err(gx, xr.grad) < 2.5e-2, "input gradient"
+    assert rel_err(gw, mod.weight.grad) < 2.5e-2, "weight gradient"
+    assert rel_err(gb, mod.bias.grad) < 2.5e-2, "bias gradient"
+
+
 @pytest.mark.parametrize("cout,shape", [(16, (1, 16, 16, 8)), (64, (2, 8, 16, 16)), (32, (1, 10, 12, 8)), (48, (1, 8, 8, 24))])
 def test_stem_kernels_vs_torch_cpu(cout, shape):
     """single-channel 3x3x3 stride-2 conv (conv_stem.hip: forward with LDS input patch, weight gradient with 4 slabs per
