@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
                                                                         int64_t S, int C, int Cv) {
   constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
   extern __shared__ float s_tab[];  // [C][4]: mean, rstd, s1, s2
-  const int n = blockIdx.y;
+  // the reduce pass that precedes this one streamed (g, y) front to back: walk BACKWARDS (last sample first, last voxel
+  // first) so the most recently read part of both tensors is re-read while it still sits in L2 / Infinity Cache
+  const int n = gridDim.y - 1 - blockIdx.y;
   for (int i = threadIdx.x; i < C; i += blockDim.x) {
     s_tab[4 * i] = mean_rstd[((int64_t)n * C + i) * 2];
     s_tab[4 * i + 1] = mean_rstd[((int64_t)n * C + i) * 2 + 1];
@@ -201,7 +203,8 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
   __syncthreads();
   const float al = alpha[0];
   const int64_t total = S * Cv;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t ir = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ir < total; ir += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = total - 1 - ir;
     const int64_t v = i / Cv;
     const int cv = (int)(i - v * Cv);
     const int64_t vox = (int64_t)n * S + v;
