@@ -315,7 +315,7 @@ class GemmLayer:
         plan.emit("ctseg_conv_igemm", d, keep=(dy, out, add))
         return out
 
-    def emit_wgrad(self, x, dy):
+    def emit_wgrad(self, x, dy, bias_done=False):
         """weight + bias gradients straight into the flat gradient buffer (deterministic split-K)."""
         plan, st = self.plan, self.plan.store
         lib = nat.lib()
@@ -358,7 +358,7 @@ class GemmLayer:
             # R[(t, co)][ci] -> W_T[ci][co][t]; the bias gradient of a transposed conv is sum over dOut: separate pass
             plan.emit("ctseg_conv_wgrad_reduce", ws.data_ptr(), nslabs, kpad_w, cn_pad, A, cg, self.T, 0, cn,
                       st.g_ptr(w), None)
-            if b is not None:
+            if b is not None and not bias_done:
                 plan.emit_colsum(dy, st.g_ptr(b))
 
 

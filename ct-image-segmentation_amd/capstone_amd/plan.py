@@ -43,8 +43,10 @@ class _NormAct:
                   y.dims[0], y.S, y.C, keep=(y, res, out))
         return out
 
-    def emit_bwd(self, g, dy_out=None, g_copy=None):
-        """g = dL/d(activation). Returns dL/dy (raw conv output); alpha's gradient goes to the flat buffer."""
+    def emit_bwd(self, g, dy_out=None, g_copy=None, colsum_out=None):
+        """g = dL/d(activation). Returns dL/dy (raw conv output); alpha's gradient goes to the flat buffer.
+        ``colsum_out``: device pointer that receives sum over voxels of dL/dy per channel (bias gradient of a transposed
+        conv feeding this norm) from the same pass."""
         plan, y = self.plan, self.y
         N, S, C = y.dims[0], y.S, y.C
         P = max(1, min(1024, math.ceil(S / 512)))
@@ -58,9 +60,15 @@ class _NormAct:
                   part.data_ptr(), P, ld, N, S, C, keep=(g, part))
         plan.emit("ctseg_instnorm_prelu_bwd_finalize", part.data_ptr(), N, P, ld, C, float(S), sums.data_ptr(),
                   plan.store.g_ptr(self.alpha), keep=(sums,))
-        plan.emit("ctseg_instnorm_prelu_bwd_apply", plan.dt, g.ptr(), g.ld, y.ptr(), y.ld, self.mr.data_ptr(), a_ptr,
-                  sums.data_ptr(), dy_out.ptr(), dy_out.ld, g_copy.ptr() if g_copy is not None else None,
-                  g_copy.ld if g_copy is not None else 0, N, S, C, keep=(dy_out, g_copy))
+        args = (plan.dt, g.ptr(), g.ld, y.ptr(), y.ld, self.mr.data_ptr(), a_ptr, sums.data_ptr(), dy_out.ptr(), dy_out.ld,
+                g_copy.ptr() if g_copy is not None else None, g_copy.ld if g_copy is not None else 0, N, S, C)
+        if colsum_out is None:
+            plan.emit("ctseg_instnorm_prelu_bwd_apply", *args, keep=(dy_out, g_copy))
+        else:
+            p_cap = N * 2048
+            cs_part = torch.zeros((p_cap, rup(C, nat.epc(plan.dt))), dtype=torch.float32, device=plan.device)
+            plan.emit("ctseg_instnorm_prelu_bwd_apply_colsum", *args, cs_part.data_ptr(), p_cap, colsum_out,
+                      keep=(dy_out, g_copy, cs_part))
         return dy_out
 
 
@@ -84,8 +92,13 @@ class _ConvBlock:
         return self.na.emit_fwd(y, stats, 0, None, out)
 
     def emit_bwd(self, g, out=None, accumulate=False, need_dx=True):
-        dy = g if self.na is None else self.na.emit_bwd(g)
-        self.gemm.emit_wgrad(self.x, dy)
+        bias = self.mod.conv.bias
+        fuse_bias = self.na is not None and self.gemm.transposed and bias is not None
+        if self.na is None:
+            dy = g
+        else:   # transposed conv: its bias gradient (sum of dOut over voxels) comes out of the norm's backward pass
+            dy = self.na.emit_bwd(g, colsum_out=self.plan.store.g_ptr(bias) if fuse_bias else None)
+        self.gemm.emit_wgrad(self.x, dy, bias_done=fuse_bias)
         self.plan.grads_ready(self.params)
         if not need_dx:
             return None

@@ -237,11 +237,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
       }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int nslabs, int kpad_w, int cn_pad, int A, int AS, int T,
+template <int NSUB>
+__global__ __launch_bounds__(32 * NSUB) void wgrad_reduce_kernel(const float* __restrict__ ws, int nslabs, int kpad_w, int cn_pad, int A, int AS, int T,
                                     int col0, int nb, float* __restrict__ dw, float* __restrict__ db) {
-  // block = 32 (k,b) elements x 8 strided sub-sums over the slabs, combined in fixed order (deterministic);
-  // consecutive threads walk b (contiguous in the slab)
-  __shared__ float s_part[8][32];
+  // block = 32 (k,b) elements x NSUB strided sub-sums over the slabs, combined in fixed order (deterministic);
+  // consecutive threads walk b (contiguous in the slab).  NSUB = 32 for the many-slab / few-element case (the stem: 1024
+  // slabs x 896 elements ran 28 blocks of 128 serial loads each)
+  __shared__ float s_part[NSUB][32];
   const int64_t total = (int64_t)(T * AS + 1) * nb;
   const int64_t slab = (int64_t)kpad_w * cn_pad;
   const int el = threadIdx.x & 31, sub = threadIdx.x >> 5;
@@ -253,14 +255,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int nslabs, in
       k = (int)(i / nb);
       b = (int)(i - (int64_t)k * nb);
       const float* p = ws + (int64_t)k * cn_pad + col0 + b;
-      for (int q = sub; q < nslabs; q += 8) s += p[q * slab];
+      for (int q = sub; q < nslabs; q += NSUB) s += p[q * slab];
     }
     s_part[sub][el] = s;
     __syncthreads();
     if (sub == 0 && i < total) {
       float t8 = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) t8 += s_part[q][el];
+      for (int q = 0; q < NSUB; ++q) t8 += s_part[q][el];
       if (k == T * AS) {
         if (db != nullptr) db[b] = t8;
       } else {
@@ -354,8 +356,12 @@ extern "C" int ctseg_conv_wgrad_reduce(const float* ws, int32_t nslabs, int32_t 
   const int64_t total = (int64_t)(T * AS + 1) * nb;
   int blocks = (int)((total + 31) / 32);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws, nslabs, kpad_w, cn_pad, A, AS, T,
-                     col0, nb, dw, db);
+  if (nslabs >= 256 && blocks <= 1024)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, ws, nslabs, kpad_w, cn_pad, A, AS, T,
+                       col0, nb, dw, db);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws, nslabs, kpad_w, cn_pad, A, AS, T,
+                       col0, nb, dw, db);
   CTSEG_LAUNCH_CHECK("wgrad_reduce");
   return 0;
 }

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void squash_masks_kernel(const uint8_t* __rest
   if (threadIdx.x < 32) s_h[threadIdx.x] = 0;
   __syncthreads();
   const uint8_t* mb = masks + (int64_t)b * K * S;
+  int bg = 0;
   const bool vec = (S % 16 == 0) && (((uintptr_t)masks % 16) == 0) && (((uintptr_t)labels % 16) == 0);
   const int64_t nchunk = (S + 15) / 16;
   for (int64_t ch = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ch < nchunk; ch += (int64_t)gridDim.x * blockDim.x) {
@@ -55,14 +56,21 @@ __global__ __launch_bounds__(256) void squash_masks_kernel(const uint8_t* __rest
         labels[(int64_t)b * S + v0 + i] = (uint8_t)l;
       }
     }
+    // histogram: background is ~99 % of a CT volume, and 64 lanes adding to ONE LDS word serialise — count it per thread
+    int nbg = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       if (v0 + i < S) {
         if (labels_i64 != nullptr) labels_i64[(int64_t)b * S + v0 + i] = lab[i];
-        if (lab[i] <= K) atomicAdd(&s_h[lab[i]], 1u);
+        if (lab[i] == 0) ++nbg;
+        else if (lab[i] <= K) atomicAdd(&s_h[lab[i]], 1u);
       }
     }
+    bg += nbg;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bg += __shfl_xor(bg, o, 64);
+  if ((threadIdx.x & 63) == 0 && bg) atomicAdd(&s_h[0], (unsigned)bg);
   __syncthreads();
   if (threadIdx.x <= K && hist != nullptr && s_h[threadIdx.x] != 0)
     atomicAdd(&hist[(int64_t)b * (K + 1) + threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
@@ -239,21 +247,20 @@ __global__ __launch_bounds__(256) void dice_counts_kernel(const uint8_t* __restr
   }
 }
 
-// part [B][P][R] -> out [B][R]; 1024 threads: 16 strided sub-sums per record entry, combined in fixed order
-__global__ __launch_bounds__(1024) void reduce_partials_f64_kernel(const double* __restrict__ part, int P, int R,
-                                                                   double* __restrict__ out) {
-  __shared__ double s[16][64];
-  const int b = blockIdx.x, r = threadIdx.x & 63, sub = threadIdx.x >> 6;
+// part [B][P][R] -> out [B][R]; one block per (record entry r, b): 256 strided sub-sums over P, combined in fixed order
+__global__ __launch_bounds__(256) void reduce_partials_f64_kernel(const double* __restrict__ part, int P, int R,
+                                                                  double* __restrict__ out) {
+  __shared__ double s[256];
+  const int r = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
   double a = 0.0;
-  if (r < R)
-    for (int p = sub; p < P; p += 16) a += part[((int64_t)b * P + p) * R + r];
-  s[sub][r] = a;
+  for (int p = t; p < P; p += 256) a += part[((int64_t)b * P + p) * R + r];
+  s[t] = a;
   __syncthreads();
-  if (sub == 0 && r < R) {
-    double t = 0.0;
-    for (int i = 0; i < 16; ++i) t += s[i][r];
-    out[(int64_t)b * R + r] = t;
+  for (int w = 128; w > 0; w >>= 1) {          // fixed pairing => deterministic
+    if (t < w) s[t] += s[t + w];
+    __syncthreads();
   }
+  if (t == 0) out[(int64_t)b * R + r] = s[0];
 }
 
 }  // namespace ctseg
@@ -376,7 +383,7 @@ extern "C" int ctseg_seg_loss(const float* logits, int32_t ld, const uint8_t* la
 
 extern "C" int ctseg_reduce_partials_f64(const double* part, int32_t B, int32_t P, int32_t R, double* out, void* stream) {
   CTSEG_REQUIRE(part && out && B > 0 && P > 0 && R > 0 && R <= 64, "reduce_partials_f64: bad arguments");
-  hipLaunchKernelGGL(reduce_partials_f64_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, part, P, R, out);
+  hipLaunchKernelGGL(reduce_partials_f64_kernel, dim3(R, B), dim3(256), 0, (hipStream_t)stream, part, P, R, out);
   CTSEG_LAUNCH_CHECK("reduce_partials_f64");
   return 0;
 }

@@ -181,16 +181,23 @@ __global__ __launch_bounds__(1024) void instnorm_prelu_bwd_finalize_kernel(const
   }
 }
 
-template <typename T>
+// COLSUM: also emit per-block column sums of dy (fp32, before storage rounding) -> cs_part[(n*gridDim.x + block)][pld]; the
+// launcher picks gridDim.x so that a thread's channel chunk is the same in every grid-stride iteration.  This is the bias
+// gradient of the ConvTranspose3d that feeds this norm (its dOut = dy), which used to cost a separate pass over dy.
+template <typename T, bool COLSUM>
 __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const char* __restrict__ g, int g_ld,
                                                                         const char* __restrict__ y, int y_ld,
                                                                         const float* __restrict__ mean_rstd,
                                                                         const float* __restrict__ alpha,
                                                                         const float* __restrict__ sums, char* __restrict__ dy,
                                                                         int dy_ld, char* __restrict__ g_copy, int g_copy_ld,
-                                                                        int64_t S, int C, int Cv) {
+                                                                        int64_t S, int C, int Cv, float* __restrict__ cs_part,
+                                                                        int pld) {
   constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
-  extern __shared__ float s_tab[];  // [C][4]: mean, rstd, s1, s2
+  extern __shared__ float s_tab[];  // [C][4]: mean, rstd, s1, s2  (+ [256][EPC] column-sum scratch when COLSUM)
+  float cs[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) cs[e] = 0.f;
   // the reduce pass that precedes this one streamed (g, y) front to back: walk BACKWARDS (last sample first, last voxel
   // first) so the most recently read part of both tensors is re-read while it still sits in L2 / Infinity Cache
   const int n = gridDim.y - 1 - blockIdx.y;
@@ -222,9 +229,28 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
         r = rstd * (dxh - s_tab[4 * c + 2] - xh * s_tab[4 * c + 3]);
       }
       o[e] = r;
+      if (COLSUM) cs[e] += r;
     }
     store_chunk<T>(dy + (vox * dy_ld + cv * EPC) * SZ, o);
     if (g_copy != nullptr) store_chunk<T>(g_copy + (vox * g_copy_ld + cv * EPC) * SZ, gv);
+  }
+  if constexpr (COLSUM) {
+    float* s_cs = s_tab + 4 * C;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s_cs[threadIdx.x * EPC + e] = cs[e];
+    __syncthreads();
+    // (gridDim.x * 256) % Cv == 0: thread t handled the same chunk column in every iteration (the sweep runs backwards from
+    // total - 1, total = S * Cv) -- fixed-order sum of the threads of each column
+    if ((int)threadIdx.x < Cv * EPC) {
+      const int cv = threadIdx.x / EPC, e = threadIdx.x % EPC;
+      const int64_t lead = (int64_t)blockIdx.x * 256;
+      float a = 0.f;
+      for (int t = 0; t < 256; ++t) {
+        const int tcv = (int)((((total - 1 - lead - t) % Cv) + Cv) % Cv);
+        if (tcv == cv) a += s_cs[t * EPC + e];
+      }
+      cs_part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * pld + cv * EPC + e] = a;
+    }
   }
 }
 
@@ -350,23 +376,52 @@ extern "C" int ctseg_instnorm_prelu_bwd_finalize(const float* partials, int32_t 
   return 0;
 }
 
+static int bwd_apply_launch(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld, const float* mean_rstd,
+                            const float* alpha, const float* sums, void* dy, int32_t dy_ld, void* g_copy, int32_t g_copy_ld, int32_t N,
+                            int64_t S, int32_t C, float* cs_part, int32_t P_cap, float* cs_out, void* stream) {
+  CTSEG_REQUIRE(g && y && mean_rstd && alpha && sums && dy && N > 0, "instnorm_prelu_bwd_apply: bad arguments");
+  CHECK_CL(dtype, C, g_ld, y_ld, dy_ld, g_copy ? g_copy_ld : dy_ld);
+  int gx = ew_blocks(S * Cv);
+  const bool colsum = cs_part != nullptr;
+  const int pld = Cv * EPC_;
+  if (colsum) {
+    CTSEG_REQUIRE(cs_out != nullptr && Cv * EPC_ <= 256 && P_cap >= N, "instnorm_prelu_bwd_apply_colsum: partial buffer");
+    if (gx > P_cap / N) gx = P_cap / N;
+    // a thread must see the same channel chunk in every grid-stride iteration: (gx * 256) % Cv == 0
+    int step = Cv;
+    while (step % 2 == 0) step /= 2;          // 256 supplies every factor of two
+    gx = gx / step * step;
+    CTSEG_REQUIRE(gx >= 1, "instnorm_prelu_bwd_apply_colsum: partial buffer too small for C=%d", C);
+  }
+  dim3 grid(gx, N);
+  const size_t sh = (4 * C + (colsum ? 256 * EPC_ : 0)) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define CTSEG_APPLY(T, CS)                                                                                                      \
+  hipLaunchKernelGGL((instnorm_prelu_bwd_apply_kernel<T, CS>), grid, dim3(256), sh, st, (const char*)g, g_ld, (const char*)y, y_ld, \
+                     mean_rstd, alpha, sums, (char*)dy, dy_ld, (char*)g_copy, g_copy_ld, S, C, Cv, cs_part, pld)
+  if (dtype == CTSEG_F32) { if (colsum) CTSEG_APPLY(float, true); else CTSEG_APPLY(float, false); }
+  else { if (colsum) CTSEG_APPLY(BF16, true); else CTSEG_APPLY(BF16, false); }
+#undef CTSEG_APPLY
+  if (colsum) hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(1024), 0, st, cs_part, gx * N, pld, C, cs_out);
+  CTSEG_LAUNCH_CHECK("instnorm_prelu_bwd_apply");
+  return 0;
+}
+
 extern "C" int ctseg_instnorm_prelu_bwd_apply(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
                                               const float* mean_rstd, const float* alpha, const float* sums, void* dy,
                                               int32_t dy_ld, void* g_copy, int32_t g_copy_ld, int32_t N, int64_t S, int32_t C,
                                               void* stream) {
-  CTSEG_REQUIRE(g && y && mean_rstd && alpha && sums && dy && N > 0, "instnorm_prelu_bwd_apply: bad arguments");
-  CHECK_CL(dtype, C, g_ld, y_ld, dy_ld, g_copy ? g_copy_ld : dy_ld);
-  dim3 grid(ew_blocks(S * Cv), N);
-  const size_t sh = 4 * C * sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == CTSEG_F32)
-    hipLaunchKernelGGL(instnorm_prelu_bwd_apply_kernel<float>, grid, dim3(256), sh, st, (const char*)g, g_ld, (const char*)y,
-                       y_ld, mean_rstd, alpha, sums, (char*)dy, dy_ld, (char*)g_copy, g_copy_ld, S, C, Cv);
-  else
-    hipLaunchKernelGGL(instnorm_prelu_bwd_apply_kernel<BF16>, grid, dim3(256), sh, st, (const char*)g, g_ld, (const char*)y,
-                       y_ld, mean_rstd, alpha, sums, (char*)dy, dy_ld, (char*)g_copy, g_copy_ld, S, C, Cv);
-  CTSEG_LAUNCH_CHECK("instnorm_prelu_bwd_apply");
-  return 0;
+  return bwd_apply_launch(dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C, nullptr, 0, nullptr,
+                          stream);
+}
+
+extern "C" int ctseg_instnorm_prelu_bwd_apply_colsum(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
+                                                     const float* mean_rstd, const float* alpha, const float* sums, void* dy,
+                                                     int32_t dy_ld, void* g_copy, int32_t g_copy_ld, int32_t N, int64_t S, int32_t C,
+                                                     float* colsum_partials, int32_t P_cap, float* colsum_out, void* stream) {
+  CTSEG_REQUIRE(colsum_partials != nullptr, "instnorm_prelu_bwd_apply_colsum: partial buffer");
+  return bwd_apply_launch(dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C, colsum_partials,
+                          P_cap, colsum_out, stream);
 }
 
 extern "C" int ctseg_colsum(int32_t dtype, const void* x, int32_t ld, int64_t rows, int32_t C, float* partials, int32_t P,

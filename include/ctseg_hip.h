@@ -127,6 +127,13 @@ int ctseg_instnorm_prelu_bwd_finalize(const float* partials, int32_t N, int32_t 
 int ctseg_instnorm_prelu_bwd_apply(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
                                    const float* mean_rstd, const float* alpha, const float* sums, void* dy, int32_t dy_ld,
                                    void* g_copy, int32_t g_copy_ld, int32_t N, int64_t S, int32_t C, void* stream);
+/* Same pass, plus the column sums of dy over all N*S voxels -> colsum_out[C] (fp32): the bias gradient of the ConvTranspose3d
+ * whose output this norm consumed (autograd: dOut.sum over voxels), without a second trip over dy.  colsum_partials: scratch of
+ * P_cap rows x roundup(C, chunk) floats (P_cap >= N; a few thousand rows keep the whole chip busy); fixed-order sums. */
+int ctseg_instnorm_prelu_bwd_apply_colsum(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
+                                          const float* mean_rstd, const float* alpha, const float* sums, void* dy, int32_t dy_ld,
+                                          void* g_copy, int32_t g_copy_ld, int32_t N, int64_t S, int32_t C, float* colsum_partials,
+                                          int32_t P_cap, float* colsum_out, void* stream);
 
 /* out[c] = sum over rows of x[row][c] (bias gradient of nn.ConvTranspose3d); partials [P][roundup(C,chunk)] fp32 scratch */
 int ctseg_colsum(int32_t dtype, const void* x, int32_t ld, int64_t rows, int32_t C, float* partials, int32_t P, float* out,

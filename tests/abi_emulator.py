@@ -179,6 +179,11 @@ class Emulator:
         if g_copy:
             self._rows(g_copy, N, S, Cp, g_copy_ld)[:] = self._rows(g, N, S, Cp, g_ld)
 
+    def instnorm_prelu_bwd_apply_colsum(self, dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C,
+                                        cs_part, p_cap, cs_out):
+        self.instnorm_prelu_bwd_apply(dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C)
+        mem(cs_out, C)[:] = self._rows(dy, N, S, C, dy_ld).reshape(-1, C).sum(0, dtype=np.float64)
+
     def colsum(self, dtype, x, ld, rows, C, partials, P, out):
         mem(out, C)[:] = cl_view(x, 1, rows, 1, 1, C, ld).reshape(rows, C).astype(np.float64).sum(0)
 
