@@ -136,49 +136,44 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_reduce_kernel(const ch
   }
 }
 
-__global__ __launch_bounds__(1024) void instnorm_prelu_bwd_finalize_kernel(const float* __restrict__ partials, int N, int P, int ld,
-                                                                            int C, double S, float* __restrict__ sums,
-                                                                            float* __restrict__ dalpha) {
-  // one block; thread = (sub, n*C + c): `subs` strided sub-sums per (n,c), combined in fixed order (deterministic)
-  __shared__ double s_acc[1024 * 3];
-  __shared__ double s_da[1024];
-  const int NC = N * C;
-  const int subs = NC >= 1024 ? 1 : 1024 / NC;
-  double da = 0.0;
-  for (int base = 0; base < NC; base += 1024 / subs * 1) {
-    const int lanes = 1024 / subs;                      // (n,c) pairs handled per sweep
-    const int i = base + (int)threadIdx.x % lanes, sub = (int)threadIdx.x / lanes;
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (i < NC && sub < subs) {
-      const int n = i / C, c = i - n * C;
-      for (int p = sub; p < P; p += subs) {
-        const float* q = partials + ((int64_t)n * P + p) * 3 * ld + c;
-        s1 += (double)q[0];
-        s2 += (double)q[ld];
-        s3 += (double)q[2 * ld];
-      }
-    }
-    s_acc[threadIdx.x * 3] = s1; s_acc[threadIdx.x * 3 + 1] = s2; s_acc[threadIdx.x * 3 + 2] = s3;
-    __syncthreads();
-    if (sub == 0 && i < NC) {
-      double t1 = 0.0, t2 = 0.0, t3 = 0.0;
-      for (int k = 0; k < subs; ++k) {
-        const int t = k * lanes + (int)threadIdx.x;
-        t1 += s_acc[t * 3]; t2 += s_acc[t * 3 + 1]; t3 += s_acc[t * 3 + 2];
-      }
-      sums[(int64_t)i * 2] = (float)(t1 / S);
-      sums[(int64_t)i * 2 + 1] = (float)(t2 / S);
-      da += t3;
-    }
-    __syncthreads();
+__global__ __launch_bounds__(256) void instnorm_prelu_bwd_finalize_kernel(const float* __restrict__ partials, int P, int ld, int C,
+                                                                           double S, float* __restrict__ sums,
+                                                                           double* __restrict__ da_part) {
+  // one block per (n, c): 256 strided sub-sums over the P partial rows, combined by a fixed tree (deterministic)
+  __shared__ double s_acc[3][256];
+  const int i = blockIdx.x, n = i / C, c = i - n * C, t = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int p = t; p < P; p += 256) {
+    const float* q = partials + ((int64_t)n * P + p) * 3 * ld + c;
+    s1 += (double)q[0];
+    s2 += (double)q[ld];
+    s3 += (double)q[2 * ld];
   }
-  s_da[threadIdx.x] = da;
+  s_acc[0][t] = s1; s_acc[1][t] = s2; s_acc[2][t] = s3;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int i = 0; i < 1024; ++i) t += s_da[i];
-    dalpha[0] = (float)t;
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) { s_acc[0][t] += s_acc[0][t + w]; s_acc[1][t] += s_acc[1][t + w]; s_acc[2][t] += s_acc[2][t + w]; }
+    __syncthreads();
   }
+  if (t == 0) {
+    sums[(int64_t)i * 2] = (float)(s_acc[0][0] / S);
+    sums[(int64_t)i * 2 + 1] = (float)(s_acc[1][0] / S);
+    da_part[i] = s_acc[2][0];
+  }
+}
+// PReLU slope gradient = sum over every (n, c) of the third partial, fixed order
+__global__ __launch_bounds__(256) void instnorm_prelu_dalpha_kernel(const double* __restrict__ da_part, int NC, float* __restrict__ dalpha) {
+  __shared__ double s_da[256];
+  const int t = threadIdx.x;
+  double a = 0.0;
+  for (int i = t; i < NC; i += 256) a += da_part[i];
+  s_da[t] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) s_da[t] += s_da[t + w];
+    __syncthreads();
+  }
+  if (t == 0) dalpha[0] = (float)s_da[0];
 }
 
 // COLSUM: also emit per-block column sums of dy (fp32, before storage rounding) -> cs_part[(n*gridDim.x + block)][pld]; the
@@ -235,21 +230,40 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
     if (g_copy != nullptr) store_chunk<T>(g_copy + (vox * g_copy_ld + cv * EPC) * SZ, gv);
   }
   if constexpr (COLSUM) {
-    float* s_cs = s_tab + 4 * C;
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) s_cs[threadIdx.x * EPC + e] = cs[e];
-    __syncthreads();
     // (gridDim.x * 256) % Cv == 0: thread t handled the same chunk column in every iteration (the sweep runs backwards from
-    // total - 1, total = S * Cv) -- fixed-order sum of the threads of each column
-    if ((int)threadIdx.x < Cv * EPC) {
-      const int cv = threadIdx.x / EPC, e = threadIdx.x % EPC;
-      const int64_t lead = (int64_t)blockIdx.x * 256;
-      float a = 0.f;
-      for (int t = 0; t < 256; ++t) {
-        const int tcv = (int)((((total - 1 - lead - t) % Cv) + Cv) % Cv);
-        if (tcv == cv) a += s_cs[t * EPC + e];
+    // total - 1, total = S * Cv); fixed-order sums of the threads of each column
+    float* s_cs = s_tab + 4 * C;
+    const int64_t lead = (int64_t)blockIdx.x * 256;
+    if ((Cv & (Cv - 1)) == 0 && Cv <= 64) {
+      // power-of-two Cv: lanes l, l + Cv, l + 2 Cv, ... of a wave share the column -> xor butterfly, then 4 waves through LDS
+#pragma unroll
+      for (int e = 0; e < EPC; ++e)
+        for (int o = 32; o >= Cv; o >>= 1) cs[e] += __shfl_xor(cs[e], o, 64);
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      if (lane < Cv) {
+        const int cv = (int)((((total - 1 - lead - lane) % Cv) + Cv) % Cv);      // same for lane + 64 w: 64 % Cv == 0
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s_cs[(wave * Cv + cv) * EPC + e] = cs[e];
       }
-      cs_part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * pld + cv * EPC + e] = a;
+      __syncthreads();
+      if ((int)threadIdx.x < Cv * EPC) {
+        const float a = s_cs[threadIdx.x] + s_cs[Cv * EPC + threadIdx.x] + s_cs[2 * Cv * EPC + threadIdx.x] +
+                        s_cs[3 * Cv * EPC + threadIdx.x];
+        cs_part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * pld + threadIdx.x] = a;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s_cs[threadIdx.x * EPC + e] = cs[e];
+      __syncthreads();
+      if ((int)threadIdx.x < Cv * EPC) {
+        const int cv = threadIdx.x / EPC, e = threadIdx.x % EPC;
+        float a = 0.f;
+        for (int t = 0; t < 256; ++t) {
+          const int tcv = (int)((((total - 1 - lead - t) % Cv) + Cv) % Cv);
+          if (tcv == cv) a += s_cs[t * EPC + e];
+        }
+        cs_part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * pld + cv * EPC + e] = a;
+      }
     }
   }
 }
@@ -368,10 +382,11 @@ extern "C" int ctseg_instnorm_prelu_bwd_reduce(int32_t dtype, const void* g, int
 }
 
 extern "C" int ctseg_instnorm_prelu_bwd_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t C, double S,
-                                                 float* sums, float* dalpha, void* stream) {
-  CTSEG_REQUIRE(partials && sums && dalpha && N > 0 && P > 0 && C > 0, "instnorm_prelu_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(instnorm_prelu_bwd_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, N, P, ld, C, S,
-                     sums, dalpha);
+                                                 double* scratch, float* sums, float* dalpha, void* stream) {
+  CTSEG_REQUIRE(partials && scratch && sums && dalpha && N > 0 && P > 0 && C > 0, "instnorm_prelu_bwd_finalize: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(instnorm_prelu_bwd_finalize_kernel, dim3(N * C), dim3(256), 0, st, partials, P, ld, C, S, sums, scratch);
+  hipLaunchKernelGGL(instnorm_prelu_dalpha_kernel, dim3(1), dim3(256), 0, st, scratch, N * C, dalpha);
   CTSEG_LAUNCH_CHECK("instnorm_prelu_bwd_finalize");
   return 0;
 }

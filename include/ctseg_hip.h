@@ -120,9 +120,9 @@ int ctseg_instnorm_prelu_fwd(int32_t dtype, const void* y, int32_t y_ld, const f
 int ctseg_instnorm_prelu_bwd_reduce(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
                                     const float* mean_rstd, const float* alpha, float* partials, int32_t P, int32_t ld,
                                     int32_t N, int64_t S, int32_t C, void* stream);
-/* partials -> sums [N][C][2] (already divided by S) and dalpha (scalar, overwritten) */
+/* partials -> sums [N][C][2] (already divided by S) and dalpha (scalar, overwritten); scratch: N*C doubles */
 int ctseg_instnorm_prelu_bwd_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t C, double S,
-                                      float* sums, float* dalpha, void* stream);
+                                      double* scratch, float* sums, float* dalpha, void* stream);
 /* backward, pass 2: dy = rstd*(dxhat - s1 - xhat*s2); optionally also copies g to g_copy (fused residual hand-off) */
 int ctseg_instnorm_prelu_bwd_apply(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
                                    const float* mean_rstd, const float* alpha, const float* sums, void* dy, int32_t dy_ld,

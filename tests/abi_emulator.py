@@ -159,7 +159,7 @@ class Emulator:
         p[:, 0, 1, :C] = (dxh * xh).sum(1)
         p[:, 0, 2, :C] = np.where(xh > 0, 0, gv * xh).sum(1)
 
-    def instnorm_prelu_bwd_finalize(self, partials, N, P, ld, C, S, sums, dalpha):
+    def instnorm_prelu_bwd_finalize(self, partials, N, P, ld, C, S, scratch, sums, dalpha):
         p = mem(partials, N * P * 3 * ld).reshape(N, P, 3, ld).astype(np.float64).sum(1)
         s = mem(sums, N * C * 2).reshape(N, C, 2)
         s[:, :, 0] = p[:, 0, :C] / S
