@@ -1,0 +1,374 @@
+// LDS-halo kernel for the STRIDE-2 3x3x3 passes with few gathered channels (gfx950, bf16):
+//   * input gradient of the top-level ConvTranspose3d(64 -> 10) = a stride-2 conv 16 -> 64 over the full-resolution gradient
+//   * Conv3d 32 -> 64+64 k3 s2 (fused [residual | unit0] of the second down block) and the level-1 transposed conv's input gradient
+// of the reference's U-Net (MONAI UNet built at capstone/volumetric/base_trainer.py:65-72).
+//
+//   out[r][n] = bias[n] + add[r][n] + sum_{tap,c} in[2 r + d(tap)][c] * W[n][tap*Cg + c],   d in {-1,0,1}^3
+//
+// The generic kernel gathers 27 x (32 or 64) bytes per output row through L2 in 16-byte requests — request-rate bound
+// (0.44 ms for the 16 -> 64 pass whose operands are 1.2 GB).  Here a workgroup stages the (2 TA + 1) x 17 x 17 input region
+// of a TA x 8 x 8 output tile once (register prefetch of the next tile under the MFMAs), streams the K-contiguous packed
+// weights through a two-slot LDS ring with direct-to-LDS loads (as conv_halo_sw.hip) and handles 64 output columns
+// (blockIdx.y picks the column block).
+//
+// LDS halo image: planes of 16-byte channel chunks, [plane][(ha * 17 + hb) * 18 + (hc ^ ((hb >> 1) & 1))][16 B].  An MFMA
+// operand row group = 2 (b) x 8 (c) output voxels = input slots two apart: 8 lanes of a b-row cover 256 B on the even (or
+// odd) 16-byte slots, and the XOR puts the other b-row (hb differs by 2) on the opposite parity: every ds_read_b128 phase
+// hits 16 distinct slots for every tap.
+#include "conv_common.h"
+
+namespace ctseg {
+
+constexpr int DH_NTHR = 512, DH_HB = 17, DH_HC = 18, DH_CN = 64, DH_KSB = DH_CN * 128;   // bytes of one 128-byte K stage of 64 rows
+
+template <int VB> struct DownCfg {
+  static constexpr int TA = 4;                      // 4 x 8 x 8 output tile, 8 waves (a 4-wave 2 x 8 x 8 variant with two workgroups per
+                                                    // CU measured 0.63 ms against 0.40 ms: a barrier per K stage costs more than the overlap gains)
+  static constexpr int HA = 2 * TA + 1;
+  static constexpr int HV = HA * DH_HB * DH_HC;
+  static constexpr int NPL = VB / 16, PLANE = HV * 16, HALO = NPL * PLANE;
+  static constexpr int CG = VB / 2;
+  static constexpr int G = 3;                       // 128-byte K stages per ring slot
+  static constexpr int WRING = 2 * G * DH_KSB;      // 49152
+  static constexpr int TOTAL = HALO + WRING + 8 * 2 * DH_CN * 4 + 64 * 4;
+};
+
+struct DownGeom {
+  int da, db, dc;            // output (row grid) extents along the tile axes
+  int xa, xb, xc;            // input extents along the tile axes
+  int ia, ib, ic;            // input voxel strides of the tile axes
+  int oa, ob, oc;            // output voxel strides of the tile axes
+  int pa, pb, pc;            // volume axis of each tile axis
+  int tbn, tcn, tiles;
+};
+
+template <int VB, bool STATS>
+__global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs P, const DownGeom G, int total_tiles) {
+  using CF = DownCfg<VB>;
+  constexpr int TA = CF::TA, HA = CF::HA, NPL = CF::NPL, PLANE = CF::PLANE, CG = CF::CG, RG = CF::G;
+  constexpr int FV = HA * 17 * 17, NCH = FV * NPL, J = (NCH + DH_NTHR - 1) / DH_NTHR;
+  constexpr int NU = (27 * CG + 31) / 32;                 // 32-wide k-steps that carry real taps
+  constexpr int NKS = (NU + 1) / 2;                       // 128-byte K stages to stream
+  constexpr int NRS = (NKS + RG - 1) / RG;                // ring stages per tile
+  // wave layout: 16 row tiles of 16 voxels, 8 waves x (2 row tiles x 4 column tiles)
+  constexpr int RT = 2, NT = VB == 32 ? 4 : 2;
+
+  __shared__ __attribute__((aligned(16))) char smem[CF::TOTAL];
+  char* const sH = smem;
+  char* const sW = smem + CF::HALO;
+  float* const sStats = reinterpret_cast<float*>(sW + CF::WRING);
+  int* const sTab = reinterpret_cast<int*>(sStats + 8 * 2 * DH_CN);   // per tap: [0,32) halo byte offset, [32,64) XOR flags
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const ctseg_conv_class& K = P.cls[0];
+  const int col0 = blockIdx.y * DH_CN;
+  const int kpad = K.kpad;
+
+  if (tid < 32) {
+    // slot of (lane voxel, tap) = lane part + tap part, except for the XOR: hc ^ s = hc + s * (hc even ? +1 : -1) with
+    // s = ((2 vb + db1) >> 1) & 1 = (vb & 1) ^ (db1 >> 1) and hc parity = dc1 parity  ->  per tap: byte offset, (db1 >> 1), +-16
+    int da1 = 1, db1 = 1, dc1 = 1;                          // phantom taps (zero weights) read the centre voxel
+    if (tid < 27) {
+      const int tp = K.taps[tid];
+      const int dv[3] = {(int)(int8_t)(tp & 0xff), (int)(int8_t)((tp >> 8) & 0xff), (int)(int8_t)((tp >> 16) & 0xff)};
+      da1 = dv[G.pa] + 1; db1 = dv[G.pb] + 1; dc1 = dv[G.pc] + 1;
+    }
+    sTab[tid] = ((da1 * DH_HB + db1) * DH_HC + dc1) * 16;
+    sTab[32 + tid] = (db1 >> 1) | ((dc1 & 1) ? 0x100 : 0);     // bit 0: h, bit 8: hc odd (step -16 instead of +16)
+  }
+
+  // ---- halo staging slots -----------------------------------------------------------------------------------------------
+  int g_byte[J], g_fabc[J], g_lds[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int idx = tid + j * DH_NTHR;
+    const int pl = (idx >> 3) % NPL, fv = (idx / (8 * NPL)) * 8 + (idx & 7);
+    const int fa = fv / (17 * 17), rem = fv - fa * (17 * 17), fb = rem / 17, fc = rem - fb * 17;
+    g_byte[j] = ((fa * G.ia + fb * G.ib + fc * G.ic) * P.g_ld + pl * 8) * 2;
+    g_fabc[j] = (fv < FV) ? (fa | (fb << 8) | (fc << 16)) : 0x7f7f7f;
+    g_lds[j] = pl * PLANE + ((fa * DH_HB + fb) * DH_HC + (fc ^ ((fb >> 1) & 1))) * 16;
+  }
+  auto tile_origin = [&](int t, int& n, int& a0, int& b0, int& c0) {
+    n = t / G.tiles;
+    int r = t - n * G.tiles;
+    const int tc = r % G.tcn; r /= G.tcn;
+    const int tb = r % G.tbn; const int ta = r / G.tbn;
+    a0 = ta * TA; b0 = tb * 8; c0 = tc * 8;
+  };
+  const int64_t in_sample = (int64_t)P.Xi * P.Yi * P.Zi, out_sample = (int64_t)P.Xo * P.Yo * P.Zo;
+  u32x4 rh[J];
+  auto gload = [&](int t) {
+    int n, a0, b0, c0;
+    tile_origin(t, n, a0, b0, c0);
+    const int ai0 = 2 * a0 - 1, bi0 = 2 * b0 - 1, ci0 = 2 * c0 - 1;       // input coordinate of halo (0,0,0)
+    const char* base = P.in + (n * in_sample + (int64_t)ai0 * G.ia + (int64_t)bi0 * G.ib + (int64_t)ci0 * G.ic) * P.g_ld * 2;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int ai = ai0 + (g_fabc[j] & 0xff), bi = bi0 + ((g_fabc[j] >> 8) & 0xff), ci = ci0 + (g_fabc[j] >> 16);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if ((unsigned)ai < (unsigned)G.xa && (unsigned)bi < (unsigned)G.xb && (unsigned)ci < (unsigned)G.xc)
+        v = *reinterpret_cast<const u32x4*>(base + g_byte[j]);
+      rh[j] = v;
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+      if ((g_fabc[j] & 0xff) != 0x7f) *reinterpret_cast<u32x4*>(sH + g_lds[j]) = rh[j];
+  };
+
+  // ---- weight stream ---------------------------------------------------------------------------------------------------
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int w_row = (tid >> 3) & (DH_NTHR / 8 - 1), w_q8 = (tid & 7) ^ ((w_row >> 1) & 7);
+  const char* const wsrc = P.w + (K.w_off + (int64_t)(col0 + w_row) * kpad + w_q8 * 8) * 2;
+  int wstage = 0;
+  auto wload = [&](int rs, int slot) {
+    char* dst = sW + slot * (RG * DH_KSB) + wave * 1024;
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      const int ks = rs * RG + g;
+      if (ks < NKS) {
+#pragma unroll
+        for (int rd = 0; rd < 512 / DH_NTHR; ++rd)         // 512 16-byte chunks per K stage of 64 rows: rows 32 rd .. 32 rd + 31
+          __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ((int64_t)rd * 32 * kpad) * 2 + (int64_t)ks * 128),
+                                           (lptr_t)(dst + g * DH_KSB + rd * (DH_NTHR * 16)), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- per-lane constants ------------------------------------------------------------------------------------------------
+  const int pb = r16 >> 3, pc = r16 & 7;
+  int va[RT], vb[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    if (VB == 32) { va[rt] = wave >> 1; vb[rt] = 2 * (2 * (wave & 1) + rt) + pb; }
+    else { va[rt] = (wave >> 1) >> 1; vb[rt] = 2 * (2 * ((wave >> 1) & 1) + rt) + pb; }
+  }
+  int lbase[RT], lpar[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    lbase[rt] = ((2 * va[rt] * DH_HB + 2 * vb[rt]) * DH_HC + 2 * pc) * 16;
+    lpar[rt] = vb[rt] & 1;
+  }
+  const int jn0 = (VB == 32) ? 0 : (wave & 1) * 2;           // first 16-column tile of this wave
+  const int wrd = r16 * 128, wswz = (r16 >> 1) & 7;
+  const bool af32 = P.add_f32 != 0;
+  const int ASZ = af32 ? 4 : 2;
+  float bias[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = col0 + (jn0 + j) * 16 + 4 * q4 + e;
+      bias[j][e] = (P.bias != nullptr && ch < P.Cn) ? P.bias[ch] : 0.f;
+    }
+  float wsum[NT][4], wsq[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { wsum[j][e] = 0.f; wsq[j][e] = 0.f; }
+  int stat_n = -1;
+  auto flush_stats = [&](int n) {
+    // each (channel) column is owned by the waves with the same jn0: VB = 32 all 8 waves; VB = 64 the 4 waves of a column half
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = wsum[j][e], b = wsq[j][e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (r16 == 0) {
+          const int c = (jn0 + j) * 16 + 4 * q4 + e;
+          sStats[(wave * 2 + 0) * DH_CN + c] = a;
+          sStats[(wave * 2 + 1) * DH_CN + c] = b;
+        }
+        wsum[j][e] = 0.f;
+        wsq[j][e] = 0.f;
+      }
+    __syncthreads();
+    if (tid < 2 * DH_CN) {
+      const int which = tid / DH_CN, c = tid % DH_CN;
+      float a = 0.f;
+      if (VB == 32) {
+#pragma unroll
+        for (int w = 0; w < DH_NTHR / 64; ++w) a += sStats[(w * 2 + which) * DH_CN + c];
+      } else {
+        const int par = (c >> 5) & 1;                           // column half -> waves with (wave & 1) == par
+#pragma unroll
+        for (int w = 0; w < 4; ++w) a += sStats[((2 * w + par) * 2 + which) * DH_CN + c];
+      }
+      const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + blockIdx.x;
+      if (col0 + c < P.stats_ld) P.stats[(slot_t * 2 + which) * P.stats_ld + col0 + c] = a;
+    }
+    __syncthreads();
+  };
+
+  const int GX = gridDim.x;
+  int first, stride, last;
+  if ((GX & 7) == 0) {
+    const int chunk = (total_tiles + 7) / 8, xcd = blockIdx.x & 7;
+    first = xcd * chunk + (blockIdx.x >> 3);
+    stride = GX >> 3;
+    last = (xcd + 1) * chunk < total_tiles ? (xcd + 1) * chunk : total_tiles;
+  } else {
+    first = blockIdx.x; stride = GX; last = total_tiles;
+  }
+
+  __syncthreads();
+  int t = first;
+  if (t < last) {
+    gload(t);
+    wload(0, 0);
+    sstore();
+  }
+  __syncthreads();
+  for (; t < last; t += stride) {
+    const int tn = t + stride;
+    int n, a0, b0, c0;
+    tile_origin(t, n, a0, b0, c0);
+    if (STATS && n != stat_n) {
+      if (stat_n >= 0) flush_stats(stat_n);
+      stat_n = n;
+    }
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int rs = 0; rs < NRS; ++rs) {
+      const int slot = wstage & 1;
+      if (rs + 1 < NRS) wload(rs + 1, slot ^ 1);
+      else if (tn < last) wload(0, slot ^ 1);
+      if (rs == 0 && tn < last) gload(tn);
+      const char* wb = sW + slot * (RG * DH_KSB) + wrd;
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int u = (rs * RG + g) * 2 + half;               // 32-wide k-step: K = 32 u + 8 q4 .. + 7
+          if (u < NU) {
+            const int kq = 32 * u + 8 * q4;
+            const int tap = kq / CG, plane = (kq % CG) >> 3;
+            const int tbase = sTab[tap] + plane * PLANE, tflag = sTab[32 + tap];
+            const int step = (tflag & 0x100) ? -16 : 16;
+            u32x4 xf[RT], wf[NT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+              xf[rt] = *reinterpret_cast<const u32x4*>(sH + lbase[rt] + tbase + (((lpar[rt] ^ tflag) & 1) ? step : 0));
+            const char* wk = wb + g * DH_KSB + (((4 * half + q4) ^ wswz) << 4);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4*>(wk + (jn0 + j) * 16 * 128);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) mma16<BF16>(acc[rt][j], wf[j], xf[rt]);
+          }
+        }
+      }
+      ++wstage;
+      __syncthreads();
+    }
+    // ---- epilogue: lane = (voxel (va, vb, pc) of row tile rt, channels (jn0 + j) * 16 + 4 q4 .. + 3) -----------------------
+    const int64_t obase = n * out_sample + (int64_t)a0 * G.oa + (int64_t)b0 * G.ob + (int64_t)c0 * G.oc;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool rv = (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
+      const int64_t vox = obase + (int64_t)va[rt] * G.oa + (int64_t)vb[rt] * G.ob + (int64_t)pc * G.oc;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int ch = col0 + (jn0 + j) * 16 + 4 * q4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[rt][j][e] + bias[j][e];
+          if (STATS && rv) { wsum[j][e] += v[e]; wsq[j][e] += v[e] * v[e]; }
+        }
+        if (rv && ch < P.Cn_store) {
+          if (P.add != nullptr) {
+            const char* ap = P.add + (vox * P.add_ld + ch) * ASZ;
+            if (af32) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap); v[0] += a4[0]; v[1] += a4[1]; v[2] += a4[2]; v[3] += a4[3]; }
+            else {
+              const u32x2 w2 = *reinterpret_cast<const u32x2*>(ap);
+              v[0] += bf2f(w2[0] & 0xffffu); v[1] += bf2f(w2[0] >> 16); v[2] += bf2f(w2[1] & 0xffffu); v[3] += bf2f(w2[1] >> 16);
+            }
+          }
+          *reinterpret_cast<u32x2*>(P.out + (vox * P.o_ld + ch) * 2) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        }
+      }
+    }
+    if (tn < last) {
+      sstore();                                              // every wave passed the last ring barrier: halo is free
+      __syncthreads();
+    }
+  }
+  if (STATS && stat_n >= 0) flush_stats(stat_n);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+static void down_geom(const ConvKArgs& a, int vb, DownGeom& g) {
+  const int ta = 4;
+  const int od[3] = {a.Xr, a.Yr, a.Zr}, id[3] = {a.Xi, a.Yi, a.Zi};
+  const int istr[3] = {a.Yi * a.Zi, a.Zi, 1}, ostr[3] = {a.Yo * a.Zo, a.Zo, 1};
+  auto waste = [&](int pa, int pb, int pc) {
+    const double padded = (double)((od[pa] + ta - 1) / ta * ta) * ((od[pb] + 7) / 8 * 8) * ((od[pc] + 7) / 8 * 8);
+    return padded / ((double)od[0] * od[1] * od[2]);
+  };
+  int pa = 0, pb = 1, pc = 2;
+  if (waste(2, 0, 1) < waste(0, 1, 2) - 1e-9) { pa = 2; pb = 0; pc = 1; }
+  g.pa = pa; g.pb = pb; g.pc = pc;
+  g.da = od[pa]; g.db = od[pb]; g.dc = od[pc];
+  g.xa = id[pa]; g.xb = id[pb]; g.xc = id[pc];
+  g.ia = istr[pa]; g.ib = istr[pb]; g.ic = istr[pc];
+  g.oa = ostr[pa]; g.ob = ostr[pb]; g.oc = ostr[pc];
+  g.tbn = (g.db + 7) / 8; g.tcn = (g.dc + 7) / 8;
+  g.tiles = ((g.da + ta - 1) / ta) * g.tbn * g.tcn;
+}
+
+bool conv_down_halo_eligible(const ConvKArgs& a, int dtype, int nclass) {
+  if (dtype != CTSEG_BF16 || a.out_f32 || nclass != 1 || a.sin != 2 || a.sout != 1) return false;
+  const int vb = a.Cg * 2;
+  // 32 gathered channels -> 128 columns was measured SLOWER than the generic kernel (128-row tiles do not amortise the 221 KB
+  // weight stream): only the 16-channel case runs here
+  if (vb != 32 || a.Cn < 48 || (a.Cn_store % 4) != 0) return false;
+  if ((a.g_ld % 8) != 0 || ((uintptr_t)a.in % 16) != 0 || ((uintptr_t)a.w % 16) != 0) return false;
+  if (a.Xo != a.Xr || a.Yo != a.Yr || a.Zo != a.Zr) return false;
+  if (2 * a.Xr - 1 > a.Xi + 1 || 2 * a.Yr - 1 > a.Yi + 1 || 2 * a.Zr - 1 > a.Zi + 1) return false;   // rows whose centre lies outside
+  if ((int64_t)a.Xi * a.Yi * a.Zi * a.g_ld * 2 >= (1ll << 31)) return false;
+  if ((int64_t)a.Xr * a.Yr * a.Zr < 2048) return false;
+  const ctseg_conv_class& k = a.cls[0];
+  if (k.ntaps != 27 || k.kpad < 27 * a.Cg || (k.kpad % 64) != 0 || (k.w_off % 8) != 0) return false;
+  for (int j = 0; j < 27; ++j)
+    for (int s = 0; s < 24; s += 8) {
+      const int d = (int)(int8_t)((k.taps[j] >> s) & 0xff);
+      if (d < -1 || d > 1) return false;
+    }
+  return true;
+}
+
+static int down_grid(const ConvKArgs& a, const DownGeom& g) {
+  const int total = g.tiles * a.N;
+  return total < 256 ? total : 256;
+}
+
+int conv_down_halo_slots(const ConvKArgs& a) {
+  DownGeom g;
+  down_geom(a, a.Cg * 2, g);
+  return down_grid(a, g);
+}
+
+void launch_conv_down_halo(ConvKArgs& a, hipStream_t st) {
+  DownGeom g;
+  const int vb = a.Cg * 2;
+  down_geom(a, vb, g);
+  a.tiles = g.tiles;
+  const int total = g.tiles * a.N;
+  const dim3 grid((unsigned)down_grid(a, g), (unsigned)((a.Cn + DH_CN - 1) / DH_CN)), blk(DH_NTHR);
+  const bool stats = a.stats != nullptr;
+  if (stats) hipLaunchKernelGGL((conv_down_halo_kernel<32, true>), grid, blk, 0, st, a, g, total);
+  else hipLaunchKernelGGL((conv_down_halo_kernel<32, false>), grid, blk, 0, st, a, g, total);
+}
+
+}  // namespace ctseg

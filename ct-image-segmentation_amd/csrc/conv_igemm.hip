@@ -351,7 +351,11 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   const bool up = !halo && conv_up_eligible(a, d->dtype, d->nclass);
   const bool stem = !halo && !up && conv_stem_eligible(a, d->dtype, d->nclass);
   const bool sw = !halo && !up && !stem && conv_halo_sw_eligible(a, d->dtype, d->nclass);
-  if (d->stats && sw) {
+  const bool down = !halo && !up && !stem && !sw && conv_down_halo_eligible(a, d->dtype, d->nclass);
+  if (d->stats && down) {
+    CTSEG_REQUIRE(d->stats_tile0 + conv_down_halo_slots(a) <= d->stats_tiles && d->stats_ld >= d->Cn,
+                  "conv_igemm: stats partial layout (stride-2 halo pass)");
+  } else if (d->stats && sw) {
     CTSEG_REQUIRE(d->stats_tile0 + conv_halo_sw_slots(a) <= d->stats_tiles && d->stats_ld >= d->Cn,
                   "conv_igemm: stats partial layout (streamed-weight halo pass)");
   } else if (d->stats && stem) {
@@ -371,6 +375,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   else if (up) launch_conv_up(a, st);
   else if (stem) launch_conv_stem(a, st);
   else if (sw) launch_conv_halo_sw(a, d->nclass, st);
+  else if (down) launch_conv_down_halo(a, st);
   else if (d->dtype == CTSEG_F32) launch_dtype<float>(a, smallc, d->nclass, st);
   else launch_dtype<BF16>(a, smallc, d->nclass, st);
   CTSEG_LAUNCH_CHECK("conv_igemm");
@@ -395,6 +400,7 @@ extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
   a.add = (const char*)d->add; a.o_ld = d->o_ld;
   if (conv_stem_eligible(a, d->dtype, d->nclass)) return conv_stem_slots(a);
   if (conv_halo_sw_eligible(a, d->dtype, d->nclass)) return conv_halo_sw_slots(a);
+  if (conv_down_halo_eligible(a, d->dtype, d->nclass)) return conv_down_halo_slots(a);
   const int SZq = d->dtype == CTSEG_F32 ? 4 : 2, EPCq = 16 / SZq;
   const bool smallq = (d->Cg % EPCq) != 0 || (d->g_ld % EPCq) != 0 || ((uintptr_t)d->in % 16) != 0;
   const int bm = tile_rows_for(d->Cn, d->dtype, d->out_f32, smallq);

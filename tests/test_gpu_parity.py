@@ -123,6 +123,29 @@ def test_streamed_weight_halo_kernel_vs_torch_cpu(kind, cin, cout, shape):
     assert rel_err(gb, mod.bias.grad) < 2.5e-2, "bias gradient"
 
 
+@pytest.mark.parametrize("kind,cin,cout,shape", [("conv_s2", 32, 128, (1, 32, 32, 24)), ("conv_s2", 32, 64, (2, 18, 40, 34)),
+                                                 ("conv_s2", 16, 64, (1, 32, 32, 16)), ("conv_s2", 16, 48, (1, 22, 36, 50)),
+                                                 ("convT", 64, 16, (1, 16, 16, 8)), ("convT", 128, 32, (1, 16, 16, 12))])
+def test_stride2_halo_kernel_vs_torch_cpu(kind, cin, cout, shape):
+    """stride-2 passes that take conv_down_halo (bf16, 16 / 32 gathered channels, >= 48 columns): Conv3d k3 s2 forward and the
+    input gradient of a ConvTranspose3d (a stride-2 conv over dOut); odd extents, both tile-axis mappings, two column blocks."""
+    torch.manual_seed(cin * 3 + cout + shape[2])
+    if kind == "convT":
+        mod = torch.nn.ConvTranspose3d(cin, cout, 3, 2, 1, output_padding=1)
+    else:
+        mod = torch.nn.Conv3d(cin, cout, 3, 2, 1)
+    x = torch.randn(shape[0], cin, *shape[1:])
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yy, gx, gw, gb = run_conv_module(mod, x, gy, BF16, DEV)
+    assert rel_err(yy, y.detach()) < 2.5e-2, "forward"
+    assert rel_err(gx, xr.grad) < 2.5e-2, "input gradient"
+    assert rel_err(gw, mod.weight.grad) < 2.5e-2, "weight gradient"
+    assert rel_err(gb, mod.bias.grad) < 2.5e-2, "bias gradient"
+
+
 @pytest.mark.parametrize("cout,shape", [(16, (1, 16, 16, 8)), (64, (2, 8, 16, 16)), (32, (1, 10, 12, 8)), (48, (1, 8, 8, 24))])
 def test_stem_kernels_vs_torch_cpu(cout, shape):
     """single-channel 3x3x3 stride-2 conv (conv_stem.hip: forward with LDS input patch, weight gradient with 4 slabs per
