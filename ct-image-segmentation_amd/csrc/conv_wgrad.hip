@@ -25,18 +25,27 @@ struct WgradKArgs {
   int taps[CTSEG_MAX_TAPS];
 };
 
-template <typename T, int BNW> struct WgradCfg {
+// GLDS (bf16, 16-byte-chunked gather, >= 64 columns): operands go global -> LDS directly (global_load_lds, no VGPR staging,
+// no ds_write pass).  The LDS image is then lane-linear (no row padding), so the bank spread the padding gave the transposed
+// reads comes from an XOR of the 32-byte column slot with the row instead, applied on the SOURCE side (which chunk a lane
+// fetches) and in the read address: 256-byte rows: slot ^ (row & 7); 128-byte rows: slot ^ ((row >> 1) & 3).
+__device__ __attribute__((aligned(16))) unsigned short g_wg_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+__device__ __attribute__((aligned(16))) unsigned short g_wg_one16[8] = {0x3f80, 0, 0, 0, 0, 0, 0, 0};   // bf16 1.0 on channel 0
+
+template <typename T, int BNW, bool SMALLC> struct WgradCfg {
   static constexpr int SZ = TT<T>::SZ;
-  static constexpr int PA = 128 * SZ + (SZ == 2 ? 32 : 64);
-  static constexpr int PD = BNW * SZ + ((SZ == 2) ? (BNW == 16 ? 64 : 32) : 64);
+  static constexpr bool GLDS = SZ == 2 && !SMALLC && BNW >= 64;
+  static constexpr int PA = GLDS ? 256 : 128 * SZ + (SZ == 2 ? 32 : 64);
+  static constexpr int PD = GLDS ? BNW * 2 : BNW * SZ + ((SZ == 2) ? (BNW == 16 ? 64 : 32) : 64);
   static constexpr int STAGE = 32 * (PA + PD);
 };
 
 template <typename T, int BNW, int WK, int WC, bool SMALLC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
   constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
-  using CF = WgradCfg<T, BNW>;
+  using CF = WgradCfg<T, BNW, SMALLC>;
   constexpr int PA = CF::PA, PD = CF::PD;
+  constexpr bool GLDS = CF::GLDS;
   constexpr int KT = 128 / WK / 16, CT = BNW / WC / 16;
   constexpr int ACPR = 128 / EPC;            // 16-byte chunks per gathered row (16 bf16 / 32 fp32)
   constexpr int AJ = 32 * ACPR / 256;        // gathered chunks per thread per stage (2 / 4)
@@ -60,7 +69,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
   const int nst = (mend > mstart) ? (mend - mstart + 31) / 32 : 0;
 
   // ---- fixed K position of this thread's gathered chunks -----------------------------------------
-  const int acc_c = tid % ACPR, arow0 = tid / ACPR;
+  const int arow0 = tid / ACPR;
+  // GLDS: the thread's LDS position is (row, tid % 16); it holds logical chunk ((slot32 ^ (row & 7)) << 1) | low
+  const int acc_c = GLDS ? (((((tid % ACPR) >> 1) ^ (arow0 & 7)) << 1) | (tid & 1)) : tid % ACPR;
   const int kpos = kblock * 128 + acc_c * EPC;
   const int ktot = P.ntaps * P.Cg;
   const int slot = kpos / P.Cg, ci = kpos - slot * P.Cg;
@@ -149,6 +160,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
       rd[j] = v;
     }
   };
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // GLDS: dy chunk this thread's LDS position holds (source-side swizzle, see WgradCfg)
+  const int d_row0 = tid / DCPR, d_pos = tid % DCPR;
+  const int d_c32 = (BNW == 128) ? ((d_pos >> 1) ^ (d_row0 & 7)) : ((d_pos >> 1) ^ ((d_row0 >> 1) & 3));
+  const int d_chunk = (d_c32 << 1) | (d_pos & 1);
+  auto gload_lds = [&](int s, int buf) {
+    const int mb = mstart + s * 32;
+    char* a = smem + buf * CF::STAGE + wave * 1024;
+    char* d = smem + buf * CF::STAGE + 32 * PA + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int m = mb + arow0 + j * ARS;
+      const char* src = reinterpret_cast<const char*>(g_wg_zero16);
+      if (m < mend) {
+        if (kvalid) {
+          const int xi = cx[j] * P.sin + dx, yi = cy[j] * P.sin + dy_, zi = cz[j] * P.sin + dz;
+          if ((unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi)
+            src = P.in + ((((nbase + xi) * P.Yi + yi) * P.Zi + zi) * P.g_ld + ci) * SZ;
+        } else if (kones) {
+          src = reinterpret_cast<const char*>(g_wg_one16);
+        }
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a + j * (ARS * PA)), 16, 0, 0);
+      cz[j] += P.sz; if (cz[j] >= P.Zr) { cz[j] -= P.Zr; ++cy[j]; }
+      cy[j] += P.sy; if (cy[j] >= P.Yr) { cy[j] -= P.Yr; ++cx[j]; }
+      cx[j] += P.sx;
+    }
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+      const int m = mb + d_row0 + j * (256 / DCPR);
+      const char* src = reinterpret_cast<const char*>(g_wg_zero16);
+      if (m < mend && col0 + d_chunk * EPC < P.d_valid) src = dbase + ((int64_t)m * P.d_ld + d_chunk * EPC) * SZ;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(d + j * 4096), 16, 0, 0);
+    }
+  };
   auto sstore = [&](int buf) {
     char* a = smem + buf * CF::STAGE;
     char* d = a + 32 * PA;
@@ -171,13 +218,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
     for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nst > 0) {
-    gload(0);
-    sstore(0);
+    if constexpr (GLDS) gload_lds(0, 0);
+    else { gload(0); sstore(0); }
   }
   __syncthreads();
   for (int s = 0; s < nst; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nst) gload(s + 1);
+    if (s + 1 < nst) {
+      if constexpr (GLDS) gload_lds(s + 1, buf ^ 1);     // streams into the other buffer while this one feeds the MFMAs
+      else gload(s + 1);
+    }
     const char* a = smem + buf * CF::STAGE;
     const char* d = a + 32 * PA;
     if constexpr (SZ == 2) {
@@ -186,7 +236,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
       bf16x8 af[KT], df[CT];
 #pragma unroll
       for (int i = 0; i < KT; ++i) {
-        const char* p = a + mrow * PA + (((wk * KT + i) * 16 + pc) << 1);
+        const char* p = GLDS ? a + mrow * PA + ((((wk * KT + i) ^ (mrow & 7)) << 5) + (pc << 1))
+                             : a + mrow * PA + (((wk * KT + i) * 16 + pc) << 1);
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 16 * PA));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -195,7 +246,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
       }
 #pragma unroll
       for (int j = 0; j < CT; ++j) {
-        const char* p = d + mrow * PD + (((wc * CT + j) * 16 + pc) << 1);
+        const char* p = GLDS ? d + mrow * PD + ((((wc * CT + j) ^ (BNW == 128 ? (mrow & 7) : ((mrow >> 1) & 3))) << 5) + (pc << 1))
+                             : d + mrow * PD + (((wc * CT + j) * 16 + pc) << 1);
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 16 * PD));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -221,7 +273,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
           for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], df[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (s + 1 < nst) sstore(buf ^ 1);
+    if constexpr (!GLDS) { if (s + 1 < nst) sstore(buf ^ 1); }
     __syncthreads();
   }
 
