@@ -28,8 +28,8 @@ def init_from_env(backend=None):
         backend = os.environ.get("CTSEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if os.environ.get("CTSEG_SINGLE_DEVICE") == "1":
         local = 0
-    if torch.cuda.is_available():
-        torch.cuda.set_device(local)
+    if torch.cuda.is_available() and (backend != "gloo" or local < torch.cuda.device_count()):
+        torch.cuda.set_device(local)       # a gloo run on CPU tensors may have more ranks than the box has GPUs
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world

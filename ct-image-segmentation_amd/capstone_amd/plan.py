@@ -8,6 +8,7 @@ Each node emits C-ABI calls into ``plan.fwd`` / ``plan.bwd`` at build time; noth
 except ``Plan.run``.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -332,20 +333,65 @@ class Plan:
         self.run(self.fwd, nat.stream_ptr())
         return self.logits
 
+    # weight-gradient work (split-K GEMM + slab reduce, transposed-conv bias sums) depends only on tensors that are final when
+    # it is recorded and feeds nothing but the flat gradient buffer: it runs on a second HIP stream, so an LDS-port-bound
+    # weight-gradient kernel shares the GPU with the HBM-bound norm passes / input-gradient convs of the next layers
+    SIDE_OPS = ("ctseg_conv_wgrad", "ctseg_conv_wgrad_reduce", "ctseg_colsum")
+
+    def _side_setup(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._side_edges = [i for i in range(len(self.bwd) + 1)
+                                if i == 0 or i == len(self.bwd) or
+                                (self.bwd[i][0] in self.SIDE_OPS) != (self.bwd[i - 1][0] in self.SIDE_OPS)]
+            self._side_ev = {}
+            self._join_ev = torch.cuda.Event()
+
     def backward(self, hooks=None):
         """runs the recorded backward; ``hooks`` = {program index: callable} fire between ops (DDP overlap)"""
         if self.inference:
             raise RuntimeError("this plan was recorded for inference (torch.no_grad()); run the forward with gradients enabled first")
-        st = nat.stream_ptr()
-        if not hooks:
-            self.run(self.bwd, st)
+        hooks = hooks or {}
+        if self.device.type != "cuda" or os.environ.get("CTSEG_SIDE_STREAM", "1") == "0":
+            st = nat.stream_ptr()
+            lo = 0
+            for idx in sorted(hooks):
+                self.run(self.bwd, st, lo, idx)
+                hooks[idx]()
+                lo = idx
+            self.run(self.bwd, st, lo)
             return
-        lo = 0
-        for idx in sorted(hooks):
-            self.run(self.bwd, st, lo, idx)
-            hooks[idx]()
-            lo = idx
-        self.run(self.bwd, st, lo)
+        self._side_setup()
+        main, side = torch.cuda.current_stream(self.device), self._side
+        st, ss = main.cuda_stream, side.cuda_stream
+        busy = False
+
+        def join():          # gradients written on the side stream become visible to what follows on the main stream
+            nonlocal busy
+            if busy:
+                self._join_ev.record(side)
+                main.wait_event(self._join_ev)
+                busy = False
+
+        n = len(self.bwd)
+        bounds = sorted(set(self._side_edges) | {i for i in hooks if 0 <= i <= n})
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            if a in hooks:
+                join()
+                hooks[a]()
+            if self.bwd[a][0] in self.SIDE_OPS:
+                ev = self._side_ev.get(a)
+                if ev is None:
+                    ev = self._side_ev[a] = torch.cuda.Event()
+                ev.record(main)                  # everything these ops read has been produced by now
+                side.wait_event(ev)
+                self.run(self.bwd, ss, a, b)
+                busy = True
+            else:
+                self.run(self.bwd, st, a, b)
+        join()
+        if n in hooks:
+            hooks[n]()
 
 
 class Engine:
