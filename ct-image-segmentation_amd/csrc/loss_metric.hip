@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void squash_masks_kernel(const uint8_t* __rest
 
 // One pass over fp32 channels-last logits.  Block (p, b) covers voxels [p*vp, (p+1)*vp) of sample b.
 // SOFT = false: cross-entropy-only fast path (the reference's 3-D default): no soft-Dice / focal sums, CE-only gradient
-template <typename GT, bool SOFT>
+// CP = extent of the per-class register arrays (12 when C <= 12 — the reference's 10 classes — else 16): fewer live registers,
+// more waves per SIMD for this latency-bound streaming pass
+template <typename GT, bool SOFT, int CP>
 __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__ logits, int ld, const uint8_t* __restrict__ labels,
                                                        int64_t S, int C, const float* __restrict__ class_weight, int do_stats,
                                                        double* __restrict__ part, int P, unsigned long long* __restrict__ cnt,
@@ -106,17 +108,17 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
   const int nld4 = ld / 4;
 
   float a_ce = 0.f, a_w = 0.f;
-  float a_p[CMAX], a_py[CMAX], a_fo[CMAX];
-  unsigned int c_in[CMAX], c_pr[CMAX], c_tr[CMAX];
+  float a_p[CP], a_py[CP], a_fo[CP];
+  unsigned int c_in[CP], c_pr[CP], c_tr[CP];
 #pragma unroll
-  for (int c = 0; c < CMAX; ++c) { a_p[c] = a_py[c] = a_fo[c] = 0.f; c_in[c] = c_pr[c] = c_tr[c] = 0u; }
+  for (int c = 0; c < CP; ++c) { a_p[c] = a_py[c] = a_fo[c] = 0.f; c_in[c] = c_pr[c] = c_tr[c] = 0u; }
 
   for (int64_t v = v0 + tid; v < v1; v += 256) {
     const int64_t vox = (int64_t)b * S + v;
-    float x[CMAX];
+    float x[CP];
     const f32x4* lp = reinterpret_cast<const f32x4*>(logits + vox * ld);
 #pragma unroll
-    for (int q = 0; q < CMAX / 4; ++q) {
+    for (int q = 0; q < CP / 4; ++q) {
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
       if (q < nld4) t = lp[q];
       x[4 * q] = t[0]; x[4 * q + 1] = t[1]; x[4 * q + 2] = t[2]; x[4 * q + 3] = t[3];
@@ -124,22 +126,22 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
     const int t = (int)labels[vox];
     float m = x[0];
 #pragma unroll
-    for (int c = 1; c < CMAX; ++c) if (c < C) m = fmaxf(m, x[c]);
-    float e[CMAX], ssum = 0.f;
+    for (int c = 1; c < CP; ++c) if (c < C) m = fmaxf(m, x[c]);
+    float e[CP], ssum = 0.f;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) { e[c] = (c < C) ? expf(x[c] - m) : 0.f; if (c < C) ssum += e[c]; }
+    for (int c = 0; c < CP; ++c) { e[c] = (c < C) ? expf(x[c] - m) : 0.f; if (c < C) ssum += e[c]; }
     // softmax THEN argmax, first maximal index (capstone/training/utils.py:19-20)
-    float pr[CMAX], best = -1.f;
+    float pr[CP], best = -1.f;
     int pred = 0;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) {
+    for (int c = 0; c < CP; ++c) {
       pr[c] = (c < C) ? e[c] / ssum : 0.f;
       if (c < C && pr[c] > best) { best = pr[c]; pred = c; }
     }
     const float lse = m + logf(ssum);
     float xt = 0.f, pt = 0.f;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) if (c == t) { xt = x[c]; pt = pr[c]; }
+    for (int c = 0; c < CP; ++c) if (c == t) { xt = x[c]; pt = pr[c]; }
     const float logpt = xt - lse;
     const float w = s_cw[t < CMAX ? t : 0];
     if (pred_out != nullptr) pred_out[vox] = (uint8_t)pred;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
       const float om = 1.f - pt;
       const float fo = -om * om * logpt;
 #pragma unroll
-      for (int c = 0; c < CMAX; ++c) {
+      for (int c = 0; c < CP; ++c) {
         if (c < C) {
           if (SOFT) a_p[c] += pr[c];
           if (c == t) { if (SOFT) { a_py[c] += pr[c]; a_fo[c] += fo; } c_tr[c] += 1u; }
@@ -161,10 +163,12 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
       const float ce_scale = s_coef[0] * w;
       // soft-Dice: dL/dp_c = a_c*[c==t] + b_c ; through softmax: p_k (g_k - sum_j g_j p_j)
       float d[CMAX];
-      if constexpr (SOFT) {
-        float gk[CMAX], dot = 0.f;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) {
+      for (int c = CP; c < CMAX; ++c) d[c] = 0.f;
+      if constexpr (SOFT) {
+        float gk[CP], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
           gk[c] = (c < C) ? (s_coef[1 + CMAX + c] + (c == t ? s_coef[1 + c] : 0.f)) : 0.f;
           dot += gk[c] * pr[c];
         }
@@ -172,13 +176,13 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
         const float om = 1.f - pt;
         const float fterm = ft * (2.f * om * pt * logpt - om * om);
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) {
+        for (int c = 0; c < CP; ++c) {
           const float ind = (c == t) ? 1.f : 0.f;
           d[c] = (c < C) ? (ce_scale * (pr[c] - ind) + pr[c] * (gk[c] - dot) + fterm * (ind - pr[c])) : 0.f;
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) d[c] = (c < C) ? ce_scale * (pr[c] - ((c == t) ? 1.f : 0.f)) : 0.f;
+        for (int c = 0; c < CP; ++c) d[c] = (c < C) ? ce_scale * (pr[c] - ((c == t) ? 1.f : 0.f)) : 0.f;
       }
       char* gp = dlogits + vox * g_ld * GSZ;
 #pragma unroll
@@ -192,7 +196,11 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
     double rec[2 + 3 * CMAX];
     rec[0] = a_ce; rec[1] = a_w;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) { rec[2 + c] = a_p[c]; rec[2 + CMAX + c] = a_py[c]; rec[2 + 2 * CMAX + c] = a_fo[c]; }
+    for (int c = 0; c < CMAX; ++c) {
+      rec[2 + c] = c < CP ? a_p[c < CP ? c : 0] : 0.f;
+      rec[2 + CMAX + c] = c < CP ? a_py[c < CP ? c : 0] : 0.f;
+      rec[2 + 2 * CMAX + c] = c < CP ? a_fo[c < CP ? c : 0] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 2 + 3 * CMAX; ++i) {
       double s = 0.0;
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
       if (lane == 0) s_part[wave][i] = s;
     }
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) {
+    for (int c = 0; c < CP; ++c) {
       unsigned int a = c_in[c], bq = c_pr[c], cq = c_tr[c];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); bq += __shfl_xor(bq, o, 64); cq += __shfl_xor(cq, o, 64); }
@@ -371,11 +379,17 @@ extern "C" int ctseg_seg_loss(const float* logits, int32_t ld, const uint8_t* la
   hipStream_t st = (hipStream_t)stream;
   const bool lite = (do_stats == 2 || do_stats == 0) && (do_grad == 2 || do_grad == 0);   // cross-entropy only
   const bool gbf = do_grad && gdtype == CTSEG_BF16;
-#define CTSEG_LOSS_LAUNCH(GT, SOFT)                                                                                          \
-  hipLaunchKernelGGL((seg_loss_kernel<GT, SOFT>), dim3(P, B), dim3(256), 0, st, logits, ld, labels, S, C, class_weight, do_stats, \
+#define CTSEG_LOSS_LAUNCH2(GT, SOFT, CP)                                                                                         \
+  hipLaunchKernelGGL((seg_loss_kernel<GT, SOFT, CP>), dim3(P, B), dim3(256), 0, st, logits, ld, labels, S, C, class_weight, do_stats, \
                      part, P, (unsigned long long*)cnt, do_grad, coef, (char*)dlogits, g_ld, pred_out)
+#define CTSEG_LOSS_LAUNCH(GT, SOFT)                                       \
+  do {                                                                    \
+    if (C <= 12 && ld <= 12) CTSEG_LOSS_LAUNCH2(GT, SOFT, 12);            \
+    else CTSEG_LOSS_LAUNCH2(GT, SOFT, 16);                                \
+  } while (0)
   if (gbf) { if (lite) CTSEG_LOSS_LAUNCH(BF16, false); else CTSEG_LOSS_LAUNCH(BF16, true); }
   else { if (lite) CTSEG_LOSS_LAUNCH(float, false); else CTSEG_LOSS_LAUNCH(float, true); }
+#undef CTSEG_LOSS_LAUNCH2
 #undef CTSEG_LOSS_LAUNCH
   CTSEG_LAUNCH_CHECK("seg_loss");
   return 0;
