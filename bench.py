@@ -125,13 +125,14 @@ def main():
 
         def run_probed(prog, stream, lo=0, hi=None):
             if prog is plan.fwd:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 orig_run(prog, stream, 0, probe_i)
                 a.record()
                 orig_run(prog, stream, probe_i, probe_i + 1)
                 b.record()
+                c.record()          # empty bracket right behind: what a pair of event records costs by itself on this stream
                 orig_run(prog, stream, probe_i + 1, None)
-                ev.append((a, b))
+                ev.append((a, b, c))
             else:
                 orig_run(prog, stream, lo, hi)
         plan.run = run_probed
@@ -164,7 +165,9 @@ def main():
                                       f"{'' if world == 1 else '/[3]'}), CrossEntropy + Dice metric + Adam",
                           "global_batch": world * B, "parallelism": f"dp{world}", "loss_last_step": loss_v}}
         if ev:
-            kms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            raw = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)
+            ovh = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev)
+            kms = raw - ovh     # launch duration = bracketed interval minus the empty-bracket interval measured beside it
             n_, x_, y_, z_ = B, H // 8, W // 8, D // 8
             flop = 2.0 * n_ * x_ * y_ * z_ * 256 * 256 * 27
             peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
@@ -175,7 +178,7 @@ def main():
                 traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": traffic, "kernel": "conv_igemm_kernel<BF16,192,256> encoder-bottleneck Conv3d 256->256 k3",
-                               "launch_ms": kms, "flop_per_launch": flop}
+                               "launch_ms": kms, "launch_ms_bracket": raw, "event_pair_ms": ovh, "flop_per_launch": flop}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 ncpu = len(os.sched_getaffinity(0))
