@@ -338,6 +338,13 @@ class Plan:
     # weight-gradient kernel shares the GPU with the HBM-bound norm passes / input-gradient convs of the next layers
     SIDE_OPS = ("ctseg_conv_wgrad", "ctseg_conv_wgrad_reduce", "ctseg_colsum")
 
+    def side_stream(self):
+        """the second HIP stream of this plan (None on CPU / when CTSEG_SIDE_STREAM=0)"""
+        if self.device.type != "cuda" or os.environ.get("CTSEG_SIDE_STREAM", "1") == "0" or self.inference:
+            return None
+        self._side_setup()
+        return self._side
+
     def _side_setup(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)

@@ -130,8 +130,20 @@ class BaseUNet3D(_Base):
         nat.require_gpu(images, "fit_step")
         eng = self.unet.engine()
         plan = eng.plan_for(images)
-        lab_u8, _, hist = segloss.squash_masks(masks, self._n_classes, want_i64=False)
-        logits = plan.forward(images)
+        side = plan.side_stream()
+        if side is not None:
+            # the label map is not needed before the loss: squash the masks on the side stream while the forward pass starts
+            main = torch.cuda.current_stream(images.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                lab_u8, _, hist = segloss.squash_masks(masks, self._n_classes, want_i64=False)
+            for t in (lab_u8, hist):
+                t.record_stream(main)
+            logits = plan.forward(images)
+            main.wait_stream(side)
+        else:
+            lab_u8, _, hist = segloss.squash_masks(masks, self._n_classes, want_i64=False)
+            logits = plan.forward(images)
         le = getattr(plan, "_ctseg_loss", None)
         if le is None:
             le = plan._ctseg_loss = segloss.SegLossEngine(images.device, images.shape[0], logits.S, self._n_classes)
