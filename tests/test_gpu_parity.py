@@ -475,3 +475,24 @@ def test_full_size_properties_bf16():
     st.adam_m.zero_(); st.adam_v.zero_(); st.step = 0
     l0b = m.fit_step((images, masks, ind)).item()
     assert l0b == l0 and torch.equal(st.flat_g, g1)
+
+
+def test_side_stream_backward_is_bit_identical(monkeypatch):
+    """weight gradients on the second HIP stream (default) vs everything on one stream: same bits in the flat gradient buffer
+    and the same updated weights (no float atomics anywhere, so stream interleaving cannot change a sum order)."""
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    g = torch.Generator().manual_seed(11)
+    images = torch.randn(2, 1, 32, 32, 16, generator=g).to(DEV)
+    masks = (torch.rand(2, 9, 32, 32, 16, generator=g) < 0.1).to(torch.uint8).to(DEV)
+    ind = torch.ones(2, 9, dtype=torch.float64).to(DEV)
+    out = []
+    for side in ("1", "0"):
+        monkeypatch.setenv("CTSEG_SIDE_STREAM", side)
+        torch.manual_seed(3)
+        m = BaseUNet3D(filters=[16, 32, 64], loss_fx=["CrossEntropy"], precision="bf16").to(DEV)
+        losses = [float(m.fit_step((images, masks, ind))) for _ in range(3)]
+        st = m.unet.engine().store
+        torch.cuda.synchronize()
+        out.append((losses, st.flat_g.clone(), st.flat_p.clone()))
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
