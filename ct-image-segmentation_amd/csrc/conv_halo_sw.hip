@@ -90,8 +90,6 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
     g_habc[j] = (fv < FV) ? (ha | (hb << 8) | (hc << 16)) : 0x7f7f7f;  // sentinel fails every bounds test
     g_lds[j] = pl * PLANE + ((ha * 10 + hb) * 10 + hc) * 16;
   }
-  const int per_sample_in = G.da * G.ia;   // not used for addressing (strides carry it); kept for clarity
-  (void)per_sample_in;
   auto tile_origin = [&](int t, int& n, int& a0, int& b0, int& c0) {
     n = t / G.tiles;
     int r = t - n * G.tiles;
