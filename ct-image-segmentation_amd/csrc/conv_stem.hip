@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
     const int64_t vb = (((int64_t)n * P.Xo + x0) * P.Yo + y0) * P.Zo + z0;
     const bool xok = x0 + wave < P.Xr, zok = z0 + pz < P.Zr;
     char* ob = P.out + vb * P.o_ld * 2;
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < 4; ++i) {   // K = 32 is ONE MFMA per 16x16 tile: operand -> MFMA -> store, row tile by row tile
       u32x4 xf;
 #pragma unroll
