@@ -104,6 +104,19 @@ def test_up_halo_kernel_vs_torch_cpu(kind, cin, cout, shape):
                                                  ("convT", 128, 32, (2, 6, 20, 12)), ("conv_s2", 32, 128, (1, 32, 32, 16)),
                                                  ("conv_s2", 32, 128, (1, 18, 40, 24))])
 def test_streamed_weight_halo_kernel_vs_torch_cpu(kind, cin, cout, shape):
+    _check_conv_module(kind, cin, cout, shape)
+
+
+@pytest.mark.parametrize("kind,cin,cout,shape", [("conv", 64, 64, (1, 1, 50, 48)), ("conv", 64, 64, (1, 300, 3, 3)),
+                                                 ("conv", 64, 64, (1, 5, 5, 100)), ("convT", 128, 32, (1, 1, 40, 52)),
+                                                 ("conv_s2", 16, 64, (1, 10, 34, 50)), ("conv_s2", 16, 64, (3, 2, 66, 66)),
+                                                 ("convT", 64, 16, (1, 17, 11, 13))])
+def test_halo_kernels_on_degenerate_extents(kind, cin, cout, shape):
+    """extents of 1-5 voxels, long thin volumes, odd sizes: every tile of the streamed-weight / stride-2 halo kernels is ragged"""
+    _check_conv_module(kind, cin, cout, shape)
+
+
+def _check_conv_module(kind, cin, cout, shape):
     """passes that take conv_halo_sw (bf16): 64->64 k3 s1 forward + input gradient (one class), ConvTranspose3d 128->32
     forward and the input gradient of a stride-2 conv 32->128 (8 parity classes); both tile-axis mappings, ragged tiles."""
     torch.manual_seed(cin + cout + shape[3])
