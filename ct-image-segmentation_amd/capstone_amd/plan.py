@@ -27,6 +27,13 @@ def _parts(conv):
     return (conv.weight, conv.bias, conv.out_channels)
 
 
+def _addend(out, accumulate):
+    """accumulate: False | True (add the current content of ``out``) | an Act (add that tensor, ``out`` may be fresh)"""
+    if accumulate is True:
+        return out
+    return accumulate if accumulate else None
+
+
 class _NormAct:
     """InstanceNorm + PReLU of one conv output: forward apply and the 3-kernel backward."""
 
@@ -104,7 +111,7 @@ class _ConvBlock:
         self.plan.grads_ready(self.params)
         if not need_dx:
             return None
-        return self.gemm.emit_dgrad(dy, out=out, add=out if accumulate else None)
+        return self.gemm.emit_dgrad(dy, out=out, add=_addend(out, accumulate))
 
 
 class _ResUnit:
@@ -194,7 +201,7 @@ class _ResUnit:
             plan.grads_ready([p for w, b, _ in self.fused.parts for p in (w, b)] + alpha0)
             if not need_dx:
                 return None
-            return self.fused.emit_dgrad(dfused, out=out, add=out if accumulate else None)
+            return self.fused.emit_dgrad(dfused, out=out, add=_addend(out, accumulate))
         g0 = self.gemms[0]
         g0.emit_wgrad(self.x, dy)
         ready = [g0.parts[0][0], g0.parts[0][1]] + alpha0
@@ -207,7 +214,7 @@ class _ResUnit:
         if self.identity:
             assert not accumulate
             return g0.emit_dgrad(dy, out=out, add=g)            # dx = g + dgrad(dy)
-        dx = g0.emit_dgrad(dy, out=out, add=out if accumulate else None)
+        dx = g0.emit_dgrad(dy, out=out, add=_addend(out, accumulate))
         return self.res_gemm.emit_dgrad(g, out=dx, add=dx)      # += dgrad of the 1x1 residual conv
 
 
@@ -255,8 +262,14 @@ class _Level:
         if self.up1 is not None:
             g = self.up1.emit_bwd(g)
         gcat = self.up0.emit_bwd(g)
-        self.sub.emit_bwd(gcat.slice(self.c1, self.c2), out=gcat.slice(0, self.c1), accumulate=True)
-        return self.down.emit_bwd(gcat.slice(0, self.c1), out=out, accumulate=accumulate, need_dx=need_dx)
+        # d(skip) = gcat[:, :c1] + d(sub input).  The sum goes to a DENSE tensor (the addend is read from the concat-gradient
+        # slice): the norm-backward passes of the down block then stream full cache lines instead of half of every line
+        if os.environ.get("CTSEG_DENSE_SKIP_GRAD", "1") != "0":
+            gskip = self.sub.emit_bwd(gcat.slice(self.c1, self.c2), out=None, accumulate=gcat.slice(0, self.c1))
+        else:
+            self.sub.emit_bwd(gcat.slice(self.c1, self.c2), out=gcat.slice(0, self.c1), accumulate=True)
+            gskip = gcat.slice(0, self.c1)
+        return self.down.emit_bwd(gskip, out=out, accumulate=accumulate, need_dx=need_dx)
 
 
 class Plan:
