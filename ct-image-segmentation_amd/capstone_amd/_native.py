@@ -51,7 +51,8 @@ class ConvDesc(C.Structure):
                 ("g_ld", C.c_int32), ("o_ld", C.c_int32), ("add_ld", C.c_int32),
                 ("sin", C.c_int32), ("sout", C.c_int32), ("out_f32", C.c_int32), ("add_f32", C.c_int32),
                 ("stats_ld", C.c_int32), ("stats_tiles", C.c_int32), ("stats_tile0", C.c_int32),
-                ("nclass", C.c_int32), ("cls", ConvClass * MAX_CLASSES)]
+                ("nclass", C.c_int32), ("cls", ConvClass * MAX_CLASSES),
+                ("out2", C.c_void_p), ("out2_col0", C.c_int32), ("o2_ld", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -70,6 +71,7 @@ _SIGS = {
     "ctseg_conv_tile_rows": (C.c_int, [_i32]),
     "ctseg_conv_tile_cols": (C.c_int, [_i32]),
     "ctseg_conv_num_tiles": (C.c_int, [C.POINTER(ConvDesc)]),
+    "ctseg_conv_split_ok": (C.c_int, [C.POINTER(ConvDesc)]),
     "ctseg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "ctseg_wgrad_tile_cols": (C.c_int, [_i32]),
     "ctseg_conv_wgrad_slabs": (C.c_int, [C.POINTER(WgradDesc)]),
@@ -115,6 +117,11 @@ def lib():
             raise NativeError("libctseg_hip.so ABI version mismatch")
         _lib = L
     return _lib
+
+
+def query(name, desc):
+    """host-only capability / sizing queries of the C ABI (tests route some of them through the ABI emulator)"""
+    return getattr(lib(), name)(desc)
 
 
 def stream_ptr():

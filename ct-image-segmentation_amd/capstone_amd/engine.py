@@ -17,6 +17,7 @@ What is fused where (see DESIGN.md for the byte accounting):
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -59,6 +60,22 @@ class Act:
     def valid(self):
         """torch view of the valid channels, logical NC[XYZ] order"""
         return self.t[..., self.c0:self.c0 + self.C].permute(0, 4, 1, 2, 3)
+
+
+class SplitAct:
+    """two dense tensors standing for one [.., c_split | ..] channel range (ctseg_conv_desc::out2): the consumers that used to
+    take interleaved channel slices of one buffer — half of every cache line — get full-line tensors instead"""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+        self.dims, self.C, self.dt = a.dims, a.C + b.C, a.dt
+
+    def slice(self, c0, C):
+        if c0 == 0 and C == self.a.C:
+            return self.a
+        if c0 == self.a.C and C == self.b.C:
+            return self.b
+        raise ValueError("a split activation can only be taken apart at its split point")
 
 
 def new_act(N, X, Y, Z, C, dt, device, ld=None, zero=True):
@@ -242,10 +259,12 @@ class GemmLayer:
             f = lambda v: (v + 2 * p - self.k) // self.s + 1
         return (N, f(X), f(Y), f(Z) if self.dims == 3 else 1)
 
-    def _desc(self, pack, classes, gathered, out, rowgrid, sin, sout, Cn, cg, bias_ptr, add, stats, out_f32):
+    def _desc(self, pack, classes, gathered, out, rowgrid, sin, sout, Cn, cg, bias_ptr, add, stats, out_f32, out2=None):
         plan = self.plan
         d = nat.ConvDesc()
         d.in_, d.w, d.bias, d.out = gathered.ptr(), plan.packer.ptr(pack), bias_ptr, out.ptr()
+        if out2 is not None:
+            d.out2, d.out2_col0, d.o2_ld = out2.ptr(), out.C, out2.ld
         d.add = add.ptr() if add is not None else None
         d.dtype = plan.dt
         d.N, d.Xi, d.Yi, d.Zi = gathered.dims
@@ -253,7 +272,7 @@ class GemmLayer:
         _, d.Xo, d.Yo, d.Zo = out.dims
         d.Cg, d.Cn = cg, Cn
         d.Cn_store = rup(Cn, 4 if out_f32 else nat.epc(plan.dt))
-        assert out.c0 + d.Cn_store <= out.ld, (self.name, out.c0, d.Cn_store, out.ld)
+        assert out2 is not None or out.c0 + d.Cn_store <= out.ld, (self.name, out.c0, d.Cn_store, out.ld)
         d.g_ld, d.o_ld = gathered.ld, out.ld
         d.add_ld = add.ld if add is not None else 0
         d.sin, d.sout = sin, sout
@@ -272,10 +291,26 @@ class GemmLayer:
             d.stats, d.stats_ld, d.stats_tiles, d.stats_tile0 = stats.partials.data_ptr(), stats.ld, stats.tiles, 0
         return d
 
-    def emit_fwd(self, x, out=None, want_stats=False, add=None, out_f32=False):
+    def _try_split(self, d, od, split_at):
+        """two dense outputs instead of one [split_at | rest] buffer where the kernel taking this pass can (stem, stride-2 halo)"""
+        if split_at is None or os.environ.get("CTSEG_SPLIT_OUT", "1") == "0":
+            return None
+        d.out2_col0 = split_at
+        if nat.query("ctseg_conv_split_ok", d) != 1:
+            d.out2_col0 = 0
+            return None
+        plan = self.plan
+        a = new_act(*od, split_at, plan.dt, plan.device)
+        b = new_act(*od, d.Cn - split_at, plan.dt, plan.device)
+        d.out, d.o_ld = a.ptr(), a.ld
+        d.out2, d.o2_ld = b.ptr(), b.ld
+        return SplitAct(a, b)
+
+    def emit_fwd(self, x, out=None, want_stats=False, add=None, out_f32=False, split_at=None):
         plan = self.plan
         self.x_dims = x.dims
         od = self.out_dims(x.dims)
+        own_out = out is None
         if out is None:
             dt = F32 if out_f32 else plan.dt
             out = new_act(*od, self.Cn, dt, plan.device)
@@ -292,14 +327,19 @@ class GemmLayer:
             assert tiles > 0
             stats = NormStats(plan, od[0], tiles, self.Cn, od[1] * od[2] * od[3])
             d.stats, d.stats_ld, d.stats_tiles, d.stats_tile0 = stats.partials.data_ptr(), stats.ld, stats.tiles, 0
+        if own_out and add is None and not out_f32:
+            sp = self._try_split(d, od, split_at)
+            if sp is not None:
+                out = sp
         plan.emit("ctseg_conv_igemm", d, keep=(x, out, add, stats))
         return out, stats
 
-    def emit_dgrad(self, dy, out=None, add=None):
+    def emit_dgrad(self, dy, out=None, add=None, split_at=None):
         """input gradient: gathered = dY (Cn channels), written = dX (cin channels)"""
         plan = self.plan
         assert self.dg_pack is not None, f"{self.name}: built without an input-gradient operand"
         xd = self.x_dims
+        own_out = out is None
         if out is None:
             out = new_act(*xd, self.cin, plan.dt, plan.device)
         assert out.dims == xd and out.C == self.cin and dy.C == self.Cn
@@ -312,6 +352,10 @@ class GemmLayer:
         else:
             rowgrid, sin, sout = xd[1:], 1, 1
         d = self._desc(self.dg_pack, self.dg_classes, dy, out, rowgrid, sin, sout, self.cin, self.cgd, None, add, None, False)
+        if own_out and add is None:
+            sp = self._try_split(d, xd, split_at)
+            if sp is not None:
+                out = sp
         plan.emit("ctseg_conv_igemm", d, keep=(dy, out, add))
         return out
 

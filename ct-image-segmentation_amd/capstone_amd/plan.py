@@ -100,7 +100,7 @@ class _ConvBlock:
         y, stats = self.gemm.emit_fwd(x, want_stats=True)
         return self.na.emit_fwd(y, stats, 0, None, out)
 
-    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True):
+    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True, split_at=None):
         bias = self.mod.conv.bias
         fuse_bias = self.na is not None and self.gemm.transposed and bias is not None
         if self.na is None:
@@ -111,7 +111,7 @@ class _ConvBlock:
         self.plan.grads_ready(self.params)
         if not need_dx:
             return None
-        return self.gemm.emit_dgrad(dy, out=out, add=_addend(out, accumulate))
+        return self.gemm.emit_dgrad(dy, out=out, add=_addend(out, accumulate), split_at=split_at)
 
 
 class _ResUnit:
@@ -157,7 +157,7 @@ class _ResUnit:
                 y, _ = g.emit_fwd(cur, out=out, add=res, out_f32=out_f32)
                 self.ys.append(y)
                 return y
-            yfull, stats = g.emit_fwd(cur, want_stats=True)
+            yfull, stats = g.emit_fwd(cur, want_stats=True, split_at=C if (i == 0 and self.fused is not None) else None)
             if i == 0 and self.fused is not None:
                 res, y, col0 = yfull.slice(0, C), yfull.slice(C, C), C
             else:
@@ -261,7 +261,7 @@ class _Level:
     def emit_bwd(self, g, out=None, accumulate=False, need_dx=True):
         if self.up1 is not None:
             g = self.up1.emit_bwd(g)
-        gcat = self.up0.emit_bwd(g)
+        gcat = self.up0.emit_bwd(g, split_at=self.c1)      # [d(skip) | d(sub output)], as two dense tensors where the kernel can
         # d(skip) = gcat[:, :c1] + d(sub input).  The sum goes to a DENSE tensor (the addend is read from the concat-gradient
         # slice): the norm-backward passes of the down block then stream full cache lines instead of half of every line
         if os.environ.get("CTSEG_DENSE_SKIP_GRAD", "1") != "0":

@@ -18,6 +18,9 @@ struct ConvKArgs {
   int out_f32, add_f32;
   int stats_ld, stats_tiles, stats_tile0;
   ctseg_conv_class cls[CTSEG_MAX_CLASSES];
+  // split output (ctseg_conv_desc::out2): columns >= out2_col0 go to out2; stem and stride-2 halo kernels only
+  char* out2;
+  int out2_col0, o2_ld;
 };
 
 template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag);

@@ -295,7 +295,9 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
               v[0] += bf2f(w2[0] & 0xffffu); v[1] += bf2f(w2[0] >> 16); v[2] += bf2f(w2[1] & 0xffffu); v[3] += bf2f(w2[1] >> 16);
             }
           }
-          *reinterpret_cast<u32x2*>(P.out + (vox * P.o_ld + ch) * 2) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          char* op = (P.out2 != nullptr && ch >= P.out2_col0) ? P.out2 + (vox * P.o2_ld + (ch - P.out2_col0)) * 2
+                                                               : P.out + (vox * P.o_ld + ch) * 2;
+          *reinterpret_cast<u32x2*>(op) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
         }
       }
     }

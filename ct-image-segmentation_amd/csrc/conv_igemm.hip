@@ -309,7 +309,8 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   CTSEG_REQUIRE(d->Xr < 65536 && d->Yr < 32768 && d->sin >= 1 && d->sin <= 2 && d->sout >= 1 && d->sout <= 2,
                 "conv_igemm: grid/stride out of range");
   CTSEG_REQUIRE((int64_t)d->Xr * d->sin < 65536 && (int64_t)d->Yr * d->sin < 32768, "conv_igemm: coordinates overflow 16 bits");
-  CTSEG_REQUIRE(d->Cn_store >= d->Cn && d->Cn_store % EPO == 0 && d->Cn_store <= d->o_ld, "conv_igemm: Cn_store %d", d->Cn_store);
+  CTSEG_REQUIRE(d->Cn_store >= d->Cn && d->Cn_store % EPO == 0 && (d->out2 ? d->out2_col0 : d->Cn_store) <= d->o_ld,
+                "conv_igemm: Cn_store %d", d->Cn_store);
   CTSEG_REQUIRE(d->o_ld % EPO == 0 && ((uintptr_t)d->out % 16) == 0, "conv_igemm: out not 16-byte chunked");
   const bool smallc = (d->Cg % EPC) != 0 || (d->g_ld % EPC) != 0 || ((uintptr_t)d->in % 16) != 0;
   CTSEG_REQUIRE(d->g_ld >= d->Cg, "conv_igemm: g_ld < Cg");
@@ -347,6 +348,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   a.out_f32 = d->out_f32; a.add_f32 = d->add_f32;
   a.stats_ld = d->stats_ld; a.stats_tiles = d->stats_tiles; a.stats_tile0 = d->stats_tile0;
   for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
+  a.out2 = (char*)d->out2; a.out2_col0 = d->out2_col0; a.o2_ld = d->o2_ld;
   const bool halo = conv_halo_eligible(a, d->dtype, d->nclass);
   const bool up = !halo && conv_up_eligible(a, d->dtype, d->nclass);
   const bool stem = !halo && !up && conv_stem_eligible(a, d->dtype, d->nclass);
@@ -370,6 +372,10 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
     CTSEG_REQUIRE(d->stats_tile0 + tiles * d->nclass <= d->stats_tiles && d->stats_ld >= ((d->Cn + bn - 1) / bn) * bn,
                   "conv_igemm: stats partial layout (need stats_ld >= roundup(Cn, tile cols))");
   }
+  if (d->out2 != nullptr)
+    CTSEG_REQUIRE((stem || down) && d->add == nullptr && d->out2_col0 > 0 && d->out2_col0 % 4 == 0 && d->out2_col0 < d->Cn_store &&
+                      d->o2_ld >= d->Cn_store - d->out2_col0 && d->o2_ld % 4 == 0 && ((uintptr_t)d->out2 % 16) == 0,
+                  "conv_igemm: out2 (split output) is not supported for this pass (ask ctseg_conv_split_ok first)");
   hipStream_t st = (hipStream_t)stream;
   if (halo) launch_conv_halo(a, d->dtype, st);
   else if (up) launch_conv_up(a, st);
@@ -383,10 +389,22 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
 }
 
 static void fill_args(const ctseg_conv_desc* d, ConvKArgs& a) {
+  a.out2 = nullptr; a.out2_col0 = 0; a.o2_ld = 0;
   a.w = (const char*)d->w; a.Cn_store = d->Cn_store;
   a.in = (const char*)d->in; a.N = d->N; a.Xi = d->Xi; a.Yi = d->Yi; a.Zi = d->Zi; a.Xr = d->Xr; a.Yr = d->Yr; a.Zr = d->Zr;
   a.Cg = d->Cg; a.Cn = d->Cn; a.g_ld = d->g_ld; a.sin = d->sin; a.sout = d->sout; a.rows = d->Xr * d->Yr * d->Zr;
   for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
+}
+
+extern "C" int ctseg_conv_split_ok(const ctseg_conv_desc* d) {
+  if (d == nullptr || d->nclass != 1 || d->add != nullptr) return 0;
+  ConvKArgs a;
+  fill_args(d, a);
+  a.out_f32 = d->out_f32; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo; a.add = nullptr; a.o_ld = d->o_ld;
+  if (conv_halo_eligible(a, d->dtype, d->nclass) || conv_up_eligible(a, d->dtype, d->nclass)) return 0;
+  if (conv_stem_eligible(a, d->dtype, d->nclass)) return 1;
+  if (conv_halo_sw_eligible(a, d->dtype, d->nclass)) return 0;
+  return conv_down_halo_eligible(a, d->dtype, d->nclass) ? 1 : 0;
 }
 
 // tiles per sample (all classes) a pass with this geometry writes InstanceNorm partials for

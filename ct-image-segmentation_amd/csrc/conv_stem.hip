@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
     const int64_t vb = (((int64_t)n * P.Xo + x0) * P.Yo + y0) * P.Zo + z0;
     const bool xok = x0 + wave < P.Xr, zok = z0 + pz < P.Zr;
     char* ob = P.out + vb * P.o_ld * 2;
+    char* ob2 = P.out2 != nullptr ? P.out2 + vb * P.o2_ld * 2 : nullptr;
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {   // K = 32 is ONE MFMA per 16x16 tile: operand -> MFMA -> store, row tile by row tile
       u32x4 xf;
@@ -186,8 +187,11 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
           if (STATS && rv) { wsum[j][e] += v[e]; wsq[j][e] += v[e] * v[e]; }
         }
         const int ch = j * 16 + 4 * q4;
-        if (rv && ch < P.Cn_store)
-          *reinterpret_cast<u32x2*>(ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        if (rv && ch < P.Cn_store) {
+          char* op = (ob2 != nullptr && ch >= P.out2_col0) ? ob2 + ((int64_t)ovox[i] * P.o2_ld + (ch - P.out2_col0)) * 2
+                                                          : ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2;
+          *reinterpret_cast<u32x2*>(op) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        }
       }
     }
     if (tn < total_tiles) stg.store(smem + (cur ^ 1) * S_INB, rg);

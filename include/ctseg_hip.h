@@ -66,6 +66,12 @@ typedef struct ctseg_conv_desc {
   int32_t stats_ld, stats_tiles, stats_tile0; /* partial layout; this call fills tiles [tile0, tile0+tiles*nclass) */
   int32_t nclass;
   ctseg_conv_class cls[CTSEG_MAX_CLASSES];
+  /* Optional split output (where ctseg_conv_split_ok() == 1): GEMM columns >= out2_col0 are written to `out2` (same voxel
+   * indexing, channel stride o2_ld, column c at channel c - out2_col0) instead of `out` — two DENSE tensors instead of
+   * two interleaved channel slices of one (the fused [residual | unit0] convolution of a down ResidualUnit, the
+   * [skip | sub] gradient of a SkipConnection's torch.cat).  out2 == NULL: feature off. */
+  void* out2;
+  int32_t out2_col0, o2_ld;
 } ctseg_conv_desc;
 
 /* Rows of the row grid / output columns one workgroup tile covers for a pass with Cn columns. */
@@ -73,6 +79,8 @@ int ctseg_conv_tile_rows(int32_t Cn);
 int ctseg_conv_tile_cols(int32_t Cn);
 /* InstanceNorm partial tiles per sample (summed over classes) that a pass with this geometry fills: size `stats` with it */
 int ctseg_conv_num_tiles(const ctseg_conv_desc* d);
+/* 1 if a pass with this geometry can take out2 / out2_col0 / o2_ld (out2_col0 must be set; pointers are ignored) */
+int ctseg_conv_split_ok(const ctseg_conv_desc* d);
 int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream);
 
 /* Weight gradient: R[tap*Cg+a][b] = sum_rows in[row*sin+d(tap)][a] * dy[row][b]; row K=ntaps*Cg of R is

@@ -55,11 +55,14 @@ class Emulator:
             getattr(self, name[len("ctseg_"):])(*args)
 
     # ---------------------------------------------------------------------------------------------
+    def conv_split_ok(self, d):
+        return int(d.nclass == 1 and not d.add and d.out2_col0 % 4 == 0)
+
     def conv_igemm(self, d):
         assert d.dtype == F32
         N, Cg, Cn, cs = d.N, d.Cg, d.Cn, d.Cn_store
         inp = cl_view(d.in_, N, d.Xi, d.Yi, d.Zi, Cg, d.g_ld)
-        out = cl_view(d.out, N, d.Xo, d.Yo, d.Zo, cs, d.o_ld)
+        out = cl_view(d.out, N, d.Xo, d.Yo, d.Zo, cs, d.o_ld) if not d.out2 else None
         add = cl_view(d.add, N, d.Xo, d.Yo, d.Zo, cs, d.add_ld) if d.add else None
         bias = mem(d.bias, Cn) if d.bias else np.zeros(Cn, np.float32)
         rg = (d.Xr, d.Yr, d.Zr)
@@ -88,7 +91,14 @@ class Emulator:
                 sl = (slice(None), slice(k.ox, k.ox + 2 * d.Xr, 2), slice(k.oy, k.oy + 2 * d.Yr, 2), slice(k.oz, k.oz + 2 * d.Zr, 2))
             if add is not None:
                 full = full + add[sl]
-            out[sl] = full
+            if d.out2:          # split output: columns >= out2_col0 go to the second tensor
+                c0 = d.out2_col0
+                out_a = cl_view(d.out, N, d.Xo, d.Yo, d.Zo, c0, d.o_ld)
+                out_b = cl_view(d.out2, N, d.Xo, d.Yo, d.Zo, cs - c0, d.o2_ld)
+                out_a[sl] = full[..., :c0]
+                out_b[sl] = full[..., c0:]
+            else:
+                out[sl] = full
 
     def conv_wgrad(self, d):
         assert d.dtype == F32
@@ -343,7 +353,10 @@ def patch_native(nat, emu):
     nat.stream_ptr = lambda: None
     orig_req = nat.require_gpu
     nat.require_gpu = lambda t, what: None
+    orig_query = nat.query
+    own = {"ctseg_conv_split_ok": emu.conv_split_ok}
+    nat.query = lambda name, d: own[name](d) if name in own else orig_query(name, d)
 
     def undo():
-        nat.call, nat.stream_ptr, nat.require_gpu = orig_call, orig_stream, orig_req
+        nat.call, nat.stream_ptr, nat.require_gpu, nat.query = orig_call, orig_stream, orig_req, orig_query
     return undo
