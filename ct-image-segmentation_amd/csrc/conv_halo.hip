@@ -31,38 +31,43 @@ __device__ __forceinline__ void patch_voxel(int r16, int& dy, int& z) {
 }
 
 template <int VB, int NT> struct HaloCfg {
+  // 64-byte voxels: one workgroup per CU (134 KB of LDS) -> 8 waves, two row tiles each, so the MFMAs of one wave cover the
+  // LDS latency of another; 32-byte voxels fit three 4-wave workgroups per CU
+  static constexpr int NW = VB == 64 ? 8 : 4, NTHR = 64 * NW, RT = 16 / NW;
   static constexpr int NPL = VB / 16;
   static constexpr int HALO = NPL * H_PLANE;
   static constexpr int BN = 16 * NT;
   static constexpr int KC = (27 * VB + 63) / 64;   // 64-byte K chunks
   static constexpr int NSTG = (KC + 1) / 2;        // 128-byte weight stages
   static constexpr int WBYTES = NSTG * BN * 128;
-  static constexpr int TOTAL = WBYTES + 2 * HALO + 4 * 2 * BN * 4 + 32 * 4;
+  static constexpr int TOTAL = WBYTES + 2 * HALO + NW * 2 * BN * 4 + 32 * 4;
 };
 
 // ADDC: the addend IS the input tensor (identity residual: out = conv(x) + x, and its gradient) — taken from the centre
 // voxel of the LDS halo instead of a second trip to HBM.
 template <typename T, int VB, int NT, bool STATS, bool ADDC>
-__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int total_tiles, int tyn, int tzn) {
+__global__ __launch_bounds__((HaloCfg<VB, NT>::NTHR)) void conv_halo_kernel(const ConvKArgs P, int total_tiles, int tyn, int tzn) {
   constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
   using CF = HaloCfg<VB, NT>;
   constexpr int NPL = CF::NPL, BN = CF::BN, KC = CF::KC, NSTG = CF::NSTG;
-  constexpr int NCH = H_HV * NPL, J = (NCH + 255) / 256;
+  constexpr int NW = CF::NW, NTHR = CF::NTHR, RT = CF::RT;
+  constexpr int NCH = H_HV * NPL, J = (NCH + NTHR - 1) / NTHR;
 
   __shared__ __attribute__((aligned(16))) char smem[CF::TOTAL];
   char* const sW = smem;
   char* const sH = smem + CF::WBYTES;
   float* const sStats = reinterpret_cast<float*>(sH + 2 * CF::HALO);
-  int* const sDelta = reinterpret_cast<int*>(sH + 2 * CF::HALO + 4 * 2 * BN * 4);
+  int* const sDelta = reinterpret_cast<int*>(sH + 2 * CF::HALO + NW * 2 * BN * 4);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wx = wave & 3, wh = wave >> 2;      // x plane of the tile, which RT of its 4 (y-pair) row tiles
   const int r16 = lane & 15, q4 = lane >> 4;
   const ctseg_conv_class& K = P.cls[0];
   const int col0 = blockIdx.y * BN;
   const int kpad = K.kpad;
 
   // ---- weights -> LDS (once per workgroup), tap offsets -> halo index deltas ---------------------------------
-  for (int idx = tid; idx < BN * NSTG * 8; idx += 256) {
+  for (int idx = tid; idx < BN * NSTG * 8; idx += NTHR) {
     const int q8 = idx & 7, row = (idx >> 3) % BN, s = idx / (8 * BN);
     const u32x4 v = *reinterpret_cast<const u32x4*>(P.w + (K.w_off + (int64_t)(col0 + row) * kpad) * SZ + s * 128 + q8 * 16);
     *reinterpret_cast<u32x4*>(sW + (s * BN + row) * 128 + ((q8 ^ ((row >> 1) & 7)) << 4)) = v;
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
   int g_byte[J], g_hxyz[J], g_lds[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    const int idx = tid + j * 256;
+    const int idx = tid + j * NTHR;
     const int pl = (idx >> 3) % NPL, hv = (idx / (8 * NPL)) * 8 + (idx & 7);
     const int hx = hv / (H_HY * H_HZ), rem = hv - hx * (H_HY * H_HZ);
     const int hy = rem / H_HZ, hz = rem - hy * H_HZ;
@@ -114,18 +119,19 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
     char* h = sH + buf * CF::HALO;
 #pragma unroll
     for (int j = 0; j < J; ++j)
-      if (J * 256 == NCH || tid + j * 256 < NCH) *reinterpret_cast<u32x4*>(h + g_lds[j]) = rh[j];
+      if (J * NTHR == NCH || tid + j * NTHR < NCH) *reinterpret_cast<u32x4*>(h + g_lds[j]) = rh[j];
   };
 
   // ---- per-lane constants of the MFMA operands and of the epilogue ---------------------------------------------------
   // row-tile i of wave w covers x = w, y in {2i, 2i+1}, z 0..7 (permuted inside the 2x8 patch, see header)
   int pdy, pz;
   patch_voxel(r16, pdy, pz);
-  int abase[4], ovox[4];
+  int abase[RT], ovox[RT], yrow[RT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    abase[i] = ((((wave + 1) * H_HY) + (2 * i + pdy + 1)) * H_HZ + (pz + 1)) * 16;
-    ovox[i] = (wave * P.Yo + 2 * i + pdy) * P.Zo + pz;       // voxel offset from the tile's first voxel
+  for (int i = 0; i < RT; ++i) {
+    yrow[i] = 2 * (wh * RT + i) + pdy;
+    abase[i] = ((((wx + 1) * H_HY) + (yrow[i] + 1)) * H_HZ + (pz + 1)) * 16;
+    ovox[i] = (wx * P.Yo + yrow[i]) * P.Zo + pz;       // voxel offset from the tile's first voxel
   }
   const int aplane = (VB == 64 ? q4 : (q4 & 1)) * H_PLANE;
   const int wrow = r16 * 128, wswz = (r16 >> 1) & 7;
@@ -167,8 +173,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
     __syncthreads();
     if (tid < 2 * BN) {
       const int which = tid / BN, c = tid % BN;
-      const float a = sStats[(0 * 2 + which) * BN + c] + sStats[(1 * 2 + which) * BN + c] + sStats[(2 * 2 + which) * BN + c] +
-                      sStats[(3 * 2 + which) * BN + c];
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) a += sStats[(w * 2 + which) * BN + c];
       const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + blockIdx.x;
       P.stats[(slot_t * 2 + which) * P.stats_ld + col0 + c] = a;
     }
@@ -181,11 +188,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
       if (stat_n >= 0) flush_stats(stat_n);
       stat_n = n;
     }
-    f32x4 acc[NT][4];
+    f32x4 acc[NT][RT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < RT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const char* h = sH + buf * CF::HALO + aplane;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
@@ -196,30 +203,30 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
         const int tap = 2 * c + (q4 >> 1);
         delta = sDelta[tap < 27 ? tap : 0];
       }
-      u32x4 xf[4], wf[NT];
+      u32x4 xf[RT], wf[NT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const u32x4*>(h + abase[i] + delta);
+      for (int i = 0; i < RT; ++i) xf[i] = *reinterpret_cast<const u32x4*>(h + abase[i] + delta);
       const char* wb = sW + ((c >> 1) * BN) * 128 + wrow + (((4 * (c & 1) + q4) ^ wswz) << 4);
 #pragma unroll
       for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4*>(wb + j * 16 * 128);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mma16<T>(acc[j][i], wf[j], xf[i]);
+        for (int i = 0; i < RT; ++i) mma16<T>(acc[j][i], wf[j], xf[i]);
     }
     // ---- epilogue straight from the accumulators: lane = (voxel of row-tile i, channels j*16 + 4*q4 .. +3) --------
     const int64_t vb = (((int64_t)n * P.Xo + x0) * P.Yo + y0) * P.Zo + z0;
-    const bool xok = x0 + wave < P.Xr, zok = z0 + pz < P.Zr;
-    bool rv[4];
+    const bool xok = x0 + wx < P.Xr, zok = z0 + pz < P.Zr;
+    bool rv[RT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rv[i] = xok && zok && (y0 + 2 * i + pdy < P.Yr);
-    u32x4 av[NT][4];
+    for (int i = 0; i < RT; ++i) rv[i] = xok && zok && (y0 + yrow[i] < P.Yr);
+    u32x4 av[NT][RT];
     if constexpr (ADDC) {
       const char* hc = sH + buf * CF::HALO;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RT; ++i) {
           const int cb = (j * 16 + 4 * q4) * SZ;          // byte offset of the lane's 4 channels inside the voxel
           const char* ap = hc + (cb >> 4) * H_PLANE + abase[i] + (cb & 15);
           u32x4 v = {0u, 0u, 0u, 0u};
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RT; ++i) {
           const int ch = col0 + j * 16 + 4 * q4;
           u32x4 v = {0u, 0u, 0u, 0u};
           if (rv[i] && ch < P.Cn_store) {
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvKArgs P, int t
     for (int j = 0; j < NT; ++j) {
       const int ch = col0 + j * 16 + 4 * q4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RT; ++i) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -356,9 +363,9 @@ template <typename T, int VB, int NT> static void launch_halo(ConvKArgs& a, hipS
   // identity residual: same tensor, same storage type, every stored channel present in the staged voxel, single column block
   const bool addc = a.add == a.in && a.add_ld == a.g_ld && (a.add_f32 != 0) == (SZ == 4) && a.Cn_store * SZ <= VB && grid.y == 1 &&
                     a.stats == nullptr;
-  if (a.stats != nullptr) hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, true, false>), grid, dim3(256), 0, st, a, total, tyn, tzn);
-  else if (addc) hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, false, true>), grid, dim3(256), 0, st, a, total, tyn, tzn);
-  else hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, false, false>), grid, dim3(256), 0, st, a, total, tyn, tzn);
+  if (a.stats != nullptr) hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, true, false>), grid, dim3(HaloCfg<VB, NT>::NTHR), 0, st, a, total, tyn, tzn);
+  else if (addc) hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, false, true>), grid, dim3(HaloCfg<VB, NT>::NTHR), 0, st, a, total, tyn, tzn);
+  else hipLaunchKernelGGL((conv_halo_kernel<T, VB, NT, false, false>), grid, dim3(HaloCfg<VB, NT>::NTHR), 0, st, a, total, tyn, tzn);
 }
 
 void launch_conv_halo(ConvKArgs& a, int dtype, hipStream_t st) {
