@@ -82,6 +82,7 @@ _SIGS = {
     "ctseg_instnorm_prelu_fwd": (C.c_int, [_i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
     "ctseg_instnorm_prelu_bwd_reduce": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     "ctseg_instnorm_prelu_bwd_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
+    "ctseg_instnorm_prelu_dalpha": (C.c_int, [_vp, _i32, _vp, _vp]),
     "ctseg_instnorm_prelu_bwd_apply": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
     "ctseg_instnorm_prelu_bwd_apply_colsum": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i64, _i32,
                                                         _vp, _i32, _vp, _vp]),

@@ -68,7 +68,7 @@ class _NormAct:
                   part.data_ptr(), P, ld, N, S, C, keep=(g, part))
         da_part = torch.zeros(N * C, dtype=torch.float64, device=plan.device)
         plan.emit("ctseg_instnorm_prelu_bwd_finalize", part.data_ptr(), N, P, ld, C, float(S), da_part.data_ptr(), sums.data_ptr(),
-                  plan.store.g_ptr(self.alpha), keep=(sums, da_part))
+                  None, keep=(sums, da_part))
         args = (plan.dt, g.ptr(), g.ld, y.ptr(), y.ld, self.mr.data_ptr(), a_ptr, sums.data_ptr(), dy_out.ptr(), dy_out.ld,
                 g_copy.ptr() if g_copy is not None else None, g_copy.ld if g_copy is not None else 0, N, S, C)
         if colsum_out is None:
@@ -78,6 +78,8 @@ class _NormAct:
             cs_part = torch.zeros((p_cap, rup(C, nat.epc(plan.dt))), dtype=torch.float32, device=plan.device)
             plan.emit("ctseg_instnorm_prelu_bwd_apply_colsum", *args, cs_part.data_ptr(), p_cap, colsum_out,
                       keep=(dy_out, g_copy, cs_part))
+        # PReLU slope gradient: nothing on the critical path needs it -> runs with the weight-gradient work on the side stream
+        plan.emit("ctseg_instnorm_prelu_dalpha", da_part.data_ptr(), N * C, plan.store.g_ptr(self.alpha))
         return dy_out
 
 
@@ -349,7 +351,7 @@ class Plan:
     # weight-gradient work (split-K GEMM + slab reduce, transposed-conv bias sums) depends only on tensors that are final when
     # it is recorded and feeds nothing but the flat gradient buffer: it runs on a second HIP stream, so an LDS-port-bound
     # weight-gradient kernel shares the GPU with the HBM-bound norm passes / input-gradient convs of the next layers
-    SIDE_OPS = ("ctseg_conv_wgrad", "ctseg_conv_wgrad_reduce", "ctseg_colsum")
+    SIDE_OPS = ("ctseg_conv_wgrad", "ctseg_conv_wgrad_reduce", "ctseg_colsum", "ctseg_instnorm_prelu_dalpha")
 
     def side_stream(self):
         """the second HIP stream of this plan (None on CPU / when CTSEG_SIDE_STREAM=0)"""

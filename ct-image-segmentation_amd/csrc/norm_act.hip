@@ -383,11 +383,18 @@ extern "C" int ctseg_instnorm_prelu_bwd_reduce(int32_t dtype, const void* g, int
 
 extern "C" int ctseg_instnorm_prelu_bwd_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t C, double S,
                                                  double* scratch, float* sums, float* dalpha, void* stream) {
-  CTSEG_REQUIRE(partials && scratch && sums && dalpha && N > 0 && P > 0 && C > 0, "instnorm_prelu_bwd_finalize: bad arguments");
+  CTSEG_REQUIRE(partials && scratch && sums && N > 0 && P > 0 && C > 0, "instnorm_prelu_bwd_finalize: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(instnorm_prelu_bwd_finalize_kernel, dim3(N * C), dim3(256), 0, st, partials, P, ld, C, S, sums, scratch);
-  hipLaunchKernelGGL(instnorm_prelu_dalpha_kernel, dim3(1), dim3(256), 0, st, scratch, N * C, dalpha);
+  if (dalpha != nullptr) hipLaunchKernelGGL(instnorm_prelu_dalpha_kernel, dim3(1), dim3(256), 0, st, scratch, N * C, dalpha);
   CTSEG_LAUNCH_CHECK("instnorm_prelu_bwd_finalize");
+  return 0;
+}
+
+extern "C" int ctseg_instnorm_prelu_dalpha(const double* scratch, int32_t NC, float* dalpha, void* stream) {
+  CTSEG_REQUIRE(scratch && dalpha && NC > 0, "instnorm_prelu_dalpha: bad arguments");
+  hipLaunchKernelGGL(instnorm_prelu_dalpha_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, NC, dalpha);
+  CTSEG_LAUNCH_CHECK("instnorm_prelu_dalpha");
   return 0;
 }
 

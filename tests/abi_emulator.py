@@ -174,7 +174,12 @@ class Emulator:
         s = mem(sums, N * C * 2).reshape(N, C, 2)
         s[:, :, 0] = p[:, 0, :C] / S
         s[:, :, 1] = p[:, 1, :C] / S
-        mem(dalpha, 1)[0] = p[:, 2, :C].sum()
+        mem(scratch, N * C, np.float64)[:] = p[:, 2, :C].reshape(-1)
+        if dalpha:
+            mem(dalpha, 1)[0] = p[:, 2, :C].sum()
+
+    def instnorm_prelu_dalpha(self, scratch, NC, dalpha):
+        mem(dalpha, 1)[0] = mem(scratch, NC, np.float64).sum()
 
     def instnorm_prelu_bwd_apply(self, dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C):
         xh, rstd = self._xhat(y, y_ld, mean_rstd, N, S, C)
