@@ -411,7 +411,7 @@ class NormStats:
         self.plan, self.N, self.tiles, self.C, self.count = plan, N, tiles, C, count
         self.ld = rup(C, 256 if C > 128 else nat.lib().ctseg_conv_tile_cols(C))   # 192x256 tile for C > 128
         self.partials = torch.zeros((N, tiles, 2, self.ld), dtype=torch.float32, device=plan.device)
-        self.scratch = torch.zeros((N, 64, 2, self.ld), dtype=torch.float64, device=plan.device)
+        self.scratch = torch.zeros(N * 64 * 2 * self.ld + N, dtype=torch.float64, device=plan.device)   # + N completion counters
 
     def emit_finalize(self, col0, C, eps=1e-5):
         mr = torch.zeros((self.N, C, 2), dtype=torch.float32, device=self.plan.device)

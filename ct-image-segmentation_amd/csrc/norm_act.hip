@@ -12,8 +12,13 @@ namespace ctseg {
 constexpr int FIN_GROUPS = 64;
 
 // level 1: partials [N][P][R*ld] fp32 -> scratch [N][64][R*ld] fp64 (group g sums tiles g*F .. g*F+F-1 in order)
-__global__ void partial_l1_kernel(const float* __restrict__ part, int P, int rowlen, double* __restrict__ scratch) {
-  const int g = blockIdx.x, n = blockIdx.y;
+// One launch: FIN_GROUPS blocks per sample sum their share of the P partial rows into `scratch` (fp64, fixed order); the block
+// that finishes last for a sample (device counter, reset for the next call) combines the groups into mean / rstd.
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __restrict__ part, int P, int ld, int col0, int C,
+                                                                double count, double eps, double* __restrict__ scratch,
+                                                                unsigned int* __restrict__ counter, float* __restrict__ mean_rstd) {
+  __shared__ int s_last;
+  const int g = blockIdx.x, n = blockIdx.y, rowlen = 2 * ld;
   const int F = (P + FIN_GROUPS - 1) / FIN_GROUPS;
   const int p0 = g * F, p1 = (p0 + F < P) ? p0 + F : P;
   for (int j = threadIdx.x; j < rowlen; j += blockDim.x) {
@@ -21,16 +26,17 @@ __global__ void partial_l1_kernel(const float* __restrict__ part, int P, int row
     for (int p = p0; p < p1; ++p) s += (double)part[((int64_t)n * P + p) * rowlen + j];
     scratch[((int64_t)n * FIN_GROUPS + g) * rowlen + j] = s;
   }
-}
-
-__global__ void instnorm_l2_kernel(const double* __restrict__ scratch, int ld, int col0, int C, double count, double eps,
-                                   float* __restrict__ mean_rstd) {
-  const int n = blockIdx.x;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(&counter[n], 1u) == (unsigned)(FIN_GROUPS - 1));
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double s = 0.0, q = 0.0;
-    for (int g = 0; g < FIN_GROUPS; ++g) {
-      s += scratch[((int64_t)n * FIN_GROUPS + g) * 2 * ld + col0 + c];
-      q += scratch[((int64_t)n * FIN_GROUPS + g) * 2 * ld + ld + col0 + c];
+    for (int gg = 0; gg < FIN_GROUPS; ++gg) {
+      s += __builtin_nontemporal_load(&scratch[((int64_t)n * FIN_GROUPS + gg) * rowlen + col0 + c]);
+      q += __builtin_nontemporal_load(&scratch[((int64_t)n * FIN_GROUPS + gg) * rowlen + ld + col0 + c]);
     }
     const double mean = s / count;
     double var = q / count - mean * mean;
@@ -38,6 +44,7 @@ __global__ void instnorm_l2_kernel(const double* __restrict__ scratch, int ld, i
     mean_rstd[((int64_t)n * C + c) * 2] = (float)mean;
     mean_rstd[((int64_t)n * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + eps));
   }
+  if (threadIdx.x == 0) counter[n] = 0u;
 }
 
 template <typename T>
@@ -338,8 +345,10 @@ extern "C" int ctseg_instnorm_finalize(const float* partials, int32_t N, int32_t
   CTSEG_REQUIRE(partials && scratch && mean_rstd && N > 0 && P > 0 && C > 0 && col0 >= 0 && col0 + C <= ld,
                 "instnorm_finalize: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(partial_l1_kernel, dim3(FIN_GROUPS, N), dim3(256), 0, st, partials, P, 2 * ld, scratch);
-  hipLaunchKernelGGL(instnorm_l2_kernel, dim3(N), dim3(256), 0, st, scratch, ld, col0, C, count, eps, mean_rstd);
+  // scratch: N * FIN_GROUPS * 2 * ld doubles of group sums, followed by N zero-initialised counters (one double slot each)
+  unsigned int* counter = reinterpret_cast<unsigned int*>(scratch + (int64_t)N * FIN_GROUPS * 2 * ld);
+  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(FIN_GROUPS, N), dim3(256), 0, st, partials, P, ld, col0, C, count, eps, scratch,
+                     counter, mean_rstd);
   CTSEG_LAUNCH_CHECK("instnorm_finalize");
   return 0;
 }

@@ -119,7 +119,8 @@ int ctseg_gather_cast(const float* src, const int32_t* idx, void* dst, int32_t d
  * (SURVEY.md §3.2).  Statistics come from the conv pass's partials. */
 /* partials [N][P][2][ld] fp32 -> mean_rstd [N][C][2] fp32 (biased variance, fp64 combine, fixed order) */
 int ctseg_instnorm_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t col0, int32_t C, double count,
-                            double eps, double* scratch /* [N][64][2][ld] */, float* mean_rstd, void* stream);
+                            double eps, double* scratch /* [N][64][2][ld] + N doubles; the tail zero-initialised once (completion counters) */,
+                            float* mean_rstd, void* stream);
 /* out = prelu((y-mean)*rstd, alpha) [+ res] ;  S = voxels per sample; mean_rstd NULL => identity norm/act skipped */
 int ctseg_instnorm_prelu_fwd(int32_t dtype, const void* y, int32_t y_ld, const float* mean_rstd, const float* alpha,
                              const void* res, int32_t res_ld, void* out, int32_t out_ld, int32_t N, int64_t S, int32_t C,
