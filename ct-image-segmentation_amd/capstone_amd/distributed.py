@@ -53,14 +53,17 @@ def split_points(ready_marks, sizes, n_total, first_fraction=0.6):
 
 
 class GradAllReducer:
-    def __init__(self, flat_g, n, ready_marks=None, sizes=None, group=None):
+    def __init__(self, flat_g, n, ready_marks=None, sizes=None, group=None, always=False):
         self.flat_g, self.n, self.group = flat_g, n, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # always=True issues the collectives on a one-rank group too (a one-GPU box can then drive RCCL's stream
+        # hand-offs against the two-stream backward; the sums are the identity there)
+        self.active = self.world > 1 or (always and dist.is_initialized())
         self.points = split_points(ready_marks, sizes, n) if ready_marks else []
         self.works, self.sent = [], 0
 
     def _launch(self, lo, hi):
-        if hi > lo and self.world > 1:
+        if hi > lo and self.active:
             self.works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def hooks(self, plan=None):
@@ -89,7 +92,7 @@ def broadcast_params(flat_p, group=None):
         dist.broadcast(flat_p, src=0, group=group)
 
 
-def attach(module, group=None):
+def attach(module, group=None, always=False):
     """make a BaseUNet3D data-parallel: identical weights on every rank + overlapped gradient all-reduce."""
     eng = module.unet.engine()
     st = eng.store
@@ -97,7 +100,7 @@ def attach(module, group=None):
     broadcast_params(st.flat_p, group)
     plan = eng.last_plan
     sizes = {st.off(p): p.numel() for p in st.params}
-    module.reducer = GradAllReducer(st.flat_g, st.n, plan.ready_marks if plan is not None else None, sizes, group)
+    module.reducer = GradAllReducer(st.flat_g, st.n, plan.ready_marks if plan is not None else None, sizes, group, always)
     if plan is not None:
         plan.packer.dirty = True
     return module.reducer

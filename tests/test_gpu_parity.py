@@ -509,3 +509,43 @@ def test_side_stream_backward_is_bit_identical(monkeypatch):
         out.append((losses, st.flat_g.clone(), st.flat_p.clone()))
     assert out[0][0] == out[1][0]
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+
+
+def test_rccl_gradient_exchange_on_one_rank_matches_plain_step(monkeypatch):
+    """backend "nccl" (= RCCL) with a one-rank group: broadcast, the chunked async all-reduce fired from the
+    backward hooks (joined with the weight-gradient side stream), the stream hand-back in finish().  The sums
+    are the identity on one rank, so losses / gradients / weights must equal the plain step bit for bit."""
+    import socket
+    import torch.distributed as dist
+    from capstone_amd import distributed as cdist
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    g = torch.Generator().manual_seed(12)
+    images = torch.randn(2, 1, 32, 32, 16, generator=g).to(DEV)
+    masks = (torch.rand(2, 9, 32, 32, 16, generator=g) < 0.1).to(torch.uint8).to(DEV)
+    ind = torch.ones(2, 9, dtype=torch.float64).to(DEV)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        out = []
+        for exchange in (False, True):
+            torch.manual_seed(4)
+            m = BaseUNet3D(filters=[16, 32, 64], loss_fx=["CrossEntropy"], precision="bf16").to(DEV)
+            losses = [float(m.fit_step((images, masks, ind)))]
+            if exchange:
+                red = cdist.attach(m, always=True)
+                assert red.active and red.points, "the readiness split must exist so a chunk goes out mid-backward"
+            losses += [float(m.fit_step((images, masks, ind))) for _ in range(3)]
+            st = m.unet.engine().store
+            torch.cuda.synchronize()
+            out.append((losses, st.flat_g.clone(), st.flat_p.clone()))
+        assert out[0][0] == out[1][0]
+        assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    finally:
+        dist.destroy_process_group()
