@@ -177,7 +177,7 @@ def main():
             if args.precision == "bf16" and (B, H, W, D) == (2, 512, 512, 48) and os.path.exists(pmc):
                 traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                               "traffic": traffic, "kernel": "conv_igemm_kernel<BF16,192,256> encoder-bottleneck Conv3d 256->256 k3",
+                               "traffic": traffic, "kernel": "conv_igemm_ring_kernel (192x256 tile, bf16) encoder-bottleneck Conv3d 256->256 k3",
                                "launch_ms": kms, "launch_ms_bracket": raw, "event_pair_ms": ovh, "flop_per_launch": flop}
         if world == 1 and not args.no_cpu_baseline:
             try:

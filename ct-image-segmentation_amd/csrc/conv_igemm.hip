@@ -284,7 +284,10 @@ template <typename T> static int launch_dtype(ConvKArgs& a, bool smallc, int ncl
   const int bm = tile_rows_for(a.Cn, TT<T>::DT, a.out_f32, smallc);
   a.tiles = (a.rows + bm - 1) / bm;
   if constexpr (TT<T>::DT == CTSEG_BF16) {
-    if (bm == 192) return launch_cfg<T, 192, 256, 2, 4>(a, false, nclass, st);
+    if (bm == 192) {
+      if (conv_ring_eligible(a, CTSEG_BF16, nclass)) { launch_conv_ring(a, nclass, st); return 0; }
+      return launch_cfg<T, 192, 256, 2, 4>(a, false, nclass, st);
+    }
   }
   if (a.Cn <= 16) return launch_cfg<T, 256, 16, 4, 1>(a, smallc, nclass, st);
   if (a.Cn <= 32) return launch_cfg<T, 256, 32, 4, 1>(a, smallc, nclass, st);

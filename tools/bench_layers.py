@@ -80,10 +80,14 @@ def main():
     if a.only:
         which, idx = a.only.split(":")
         name, fn, args = progs[which][int(idx)]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn(*args, st)
+        e0.record()
         for _ in range(a.loop):
             fn(*args, st)
+        e1.record()
         torch.cuda.synchronize()
-        print("looped", which, idx, name, describe(name, args, plan.dt)[0])
+        print("looped", which, idx, name, describe(name, args, plan.dt)[0], f"avg {e0.elapsed_time(e1) / a.loop:.4f} ms back-to-back")
         return
     total = 0.0
     for which, prog in progs.items():
