@@ -72,6 +72,8 @@ _SIGS = {
     "ctseg_conv_tile_cols": (C.c_int, [_i32]),
     "ctseg_conv_num_tiles": (C.c_int, [C.POINTER(ConvDesc)]),
     "ctseg_conv_split_ok": (C.c_int, [C.POINTER(ConvDesc)]),
+    "ctseg_conv_narrow_ok": (C.c_int, [C.POINTER(ConvDesc)]),
+    "ctseg_wgrad_narrow_ok": (C.c_int, [C.POINTER(WgradDesc)]),
     "ctseg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "ctseg_wgrad_tile_cols": (C.c_int, [_i32]),
     "ctseg_conv_wgrad_slabs": (C.c_int, [C.POINTER(WgradDesc)]),

@@ -78,8 +78,22 @@ class SplitAct:
         raise ValueError("a split activation can only be taken apart at its split point")
 
 
+class NarrowUnsupported(Exception):
+    """a pass of the plan being built cannot move 12-wide rows: the plan is rebuilt with 16-byte chunked rows"""
+
+
+NARROW_ROWS = [False]     # set while a Plan is being recorded (Engine.plan_for_shape)
+
+
+def default_ld(C, dt):
+    """channel stride of a fresh activation: 16-byte chunks; bf16 tensors of 9..12 channels 12 wide while NARROW_ROWS"""
+    if NARROW_ROWS[0] and dt == BF16 and rup(C, 4) == 12:
+        return 12
+    return rup(C, nat.epc(dt))
+
+
 def new_act(N, X, Y, Z, C, dt, device, ld=None, zero=True):
-    ld = ld if ld is not None else rup(C, nat.epc(dt))
+    ld = ld if ld is not None else default_ld(C, dt)
     f = torch.zeros if zero else torch.empty
     return Act(f((N, X, Y, Z, ld), dtype=nat.torch_dtype(dt), device=device), C, 0, dt)
 
@@ -271,10 +285,13 @@ class GemmLayer:
         d.Xr, d.Yr, d.Zr = rowgrid
         _, d.Xo, d.Yo, d.Zo = out.dims
         d.Cg, d.Cn = cg, Cn
-        d.Cn_store = rup(Cn, 4 if out_f32 else nat.epc(plan.dt))
+        narrow_out = plan.dt == BF16 and not out_f32 and out.ld == 12
+        d.Cn_store = rup(Cn, 4 if (out_f32 or narrow_out) else nat.epc(plan.dt))
         assert out2 is not None or out.c0 + d.Cn_store <= out.ld, (self.name, out.c0, d.Cn_store, out.ld)
         d.g_ld, d.o_ld = gathered.ld, out.ld
         d.add_ld = add.ld if add is not None else 0
+        self._narrow = plan.dt == BF16 and (narrow_out or gathered.ld == 12 or
+                                           (add is not None and add.t.dtype != torch.float32 and add.ld == 12))
         d.sin, d.sout = sin, sout
         d.out_f32 = 1 if out_f32 else 0
         d.add_f32 = 1 if (add is not None and add.t.dtype == torch.float32 and plan.dt != F32) else 0
@@ -289,6 +306,8 @@ class GemmLayer:
             assert c.kpad % bk == 0
         if stats is not None:
             d.stats, d.stats_ld, d.stats_tiles, d.stats_tile0 = stats.partials.data_ptr(), stats.ld, stats.tiles, 0
+        if self._narrow and nat.query("ctseg_conv_narrow_ok", d) != 1:
+            raise NarrowUnsupported(self.name)
         return d
 
     def _try_split(self, d, od, split_at):
@@ -386,6 +405,8 @@ class GemmLayer:
         for j, (_, off) in enumerate(self.wg_taps):
             d.taps[j] = off
         d.splits, d.kpad_w, d.cn_pad = splits, kpad_w, cn_pad
+        if plan.dt == BF16 and (gathered.ld == 12 or dyy.ld == 12) and nat.query("ctseg_wgrad_narrow_ok", d) != 1:
+            raise NarrowUnsupported(self.name + " (weight gradient)")
         nslabs = lib.ctseg_conv_wgrad_slabs(d)     # N*splits, or one per persistent workgroup (LDS-halo kernel)
         assert nslabs > 0
         ws = torch.zeros(nslabs * kpad_w * cn_pad, dtype=torch.float32, device=plan.device)

@@ -108,7 +108,10 @@ class _ConvBlock:
         if self.na is None:
             dy = g
         else:   # transposed conv: its bias gradient (sum of dOut over voxels) comes out of the norm's backward pass
-            dy = self.na.emit_bwd(g, colsum_out=self.plan.store.g_ptr(bias) if fuse_bias else None)
+            # dOut feeds the generic weight-gradient kernel and the stride-2 input-gradient pass: 16-byte chunked rows
+            y = self.na.y
+            dy_wide = new_act(*y.dims, y.C, self.plan.dt, self.plan.device, ld=rup(y.C, nat.epc(self.plan.dt)))
+            dy = self.na.emit_bwd(g, dy_out=dy_wide, colsum_out=self.plan.store.g_ptr(bias) if fuse_bias else None)
         self.gemm.emit_wgrad(self.x, dy, bias_done=fuse_bias)
         self.plan.grads_ready(self.params)
         if not need_dx:
@@ -478,9 +481,23 @@ class Engine:
         key = (N,) + sp
         plan = self.plans.get(key) or (self.plans.get(key + ("inference",)) if inference else None)
         if plan is None:
-            plan = self.plans[key + (("inference",) if inference else ())] = Plan(self, N, *sp, inference=inference)
+            plan = self.plans[key + (("inference",) if inference else ())] = self._record(N, sp, inference)
         self.last_plan = plan
         return plan
+
+    def _record(self, N, sp, inference):
+        """record a Plan; bf16 tensors of 9..12 channels (the class logits' neighbours) are laid out 12 wide when every pass
+        that touches them can move such rows (ctseg_conv_narrow_ok / ctseg_wgrad_narrow_ok), 16 wide otherwise"""
+        from . import engine as eng
+        if self.dt == BF16 and os.environ.get("CTSEG_NARROW_ROWS", "1") != "0":
+            eng.NARROW_ROWS[0] = True
+            try:
+                return Plan(self, N, *sp, inference=inference)
+            except eng.NarrowUnsupported:
+                pass
+            finally:
+                eng.NARROW_ROWS[0] = False
+        return Plan(self, N, *sp, inference=inference)
 
     # ---- raw (no autograd) API used by the native training step, bench and tests ----
     def forward(self, x):

@@ -94,6 +94,7 @@ __global__ __launch_bounds__((HaloCfg<VB, NT>::NTHR)) void conv_halo_kernel(cons
     g_hxyz[j] = (idx < NCH) ? (hx | (hy << 8) | (hz << 16)) : 0x7f7f7f;   // sentinel fails every bounds test
     g_lds[j] = pl * H_PLANE + hv * 16;
   }
+  const bool ld12 = VB == 32 && SZ == 2 && (P.g_ld & 7) != 0;   // workgroup-uniform
   const int tiles_per_sample = P.tiles;
   auto tile_origin = [&](int t, int& n, int& x0, int& y0, int& z0) {
     n = t / tiles_per_sample;
@@ -110,8 +111,13 @@ __global__ __launch_bounds__((HaloCfg<VB, NT>::NTHR)) void conv_halo_kernel(cons
     for (int j = 0; j < J; ++j) {
       const int xi = x0 - 1 + (g_hxyz[j] & 0xff), yi = y0 - 1 + ((g_hxyz[j] >> 8) & 0xff), zi = z0 - 1 + (g_hxyz[j] >> 16);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if ((unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi)
-        v = *reinterpret_cast<const u32x4*>(base + g_byte[j]);
+      if ((unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi) {
+        if (!ld12) {
+          v = *reinterpret_cast<const u32x4*>(base + g_byte[j]);
+        } else {
+          v = load_row12_chunk(base + g_byte[j], g_lds[j] >= H_PLANE);   // 24-byte rows: chunk 1 is channels 8..11 + zeros
+        }
+      }
       rh[j] = v;
     }
   };
@@ -323,7 +329,8 @@ bool conv_halo_eligible(const ConvKArgs& a, int dtype, int nclass) {
   const int vb = a.Cg * SZ;
   if (nclass != 1 || a.cls[0].ntaps != 27 || a.sin != 1 || a.sout != 1) return false;
   if (!(vb == 32 || vb == 64) || a.Cn > 32) return false;
-  if ((a.g_ld * SZ) % 16 != 0 || ((uintptr_t)a.in % 16) != 0) return false;
+  // gathered rows: 16-byte chunked, or 12 bf16 wide (24 bytes) for the 32-byte-voxel kernel
+  if (((a.g_ld * SZ) % 16 != 0 && !(vb == 32 && SZ == 2 && a.g_ld == 12)) || ((uintptr_t)a.in % 16) != 0) return false;
   if (a.Xr != a.Xi || a.Yr != a.Yi || a.Zr != a.Zi || a.Zr < 4) return false;
   if ((int64_t)a.Xi * a.Yi * a.Zi * a.g_ld * SZ >= (1ll << 31)) return false;   // per-sample byte offsets are 32-bit
   for (int j = 0; j < 27; ++j) {

@@ -312,14 +312,21 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   CTSEG_REQUIRE(d->Xr < 65536 && d->Yr < 32768 && d->sin >= 1 && d->sin <= 2 && d->sout >= 1 && d->sout <= 2,
                 "conv_igemm: grid/stride out of range");
   CTSEG_REQUIRE((int64_t)d->Xr * d->sin < 65536 && (int64_t)d->Yr * d->sin < 32768, "conv_igemm: coordinates overflow 16 bits");
-  CTSEG_REQUIRE(d->Cn_store >= d->Cn && d->Cn_store % EPO == 0 && (d->out2 ? d->out2_col0 : d->Cn_store) <= d->o_ld,
+  // "narrow" bf16 rows: 12 elements (24 bytes) for tensors of 9..12 channels (the 10 classes of the reference).  Only the
+  // LDS-halo passes move them (8-byte pieces); everything else wants 16-byte chunked rows (ctseg_conv_narrow_ok tells).
+  const bool n_out = SZ == 2 && !d->out_f32 && (d->o_ld % EPO != 0 || d->Cn_store % EPO != 0);
+  const bool n_in = SZ == 2 && d->g_ld == 12 && d->Cg == 16;
+  const bool n_add = SZ == 2 && d->add != nullptr && !d->add_f32 && d->add_ld % EPO != 0;
+  const int EPOv = n_out ? 4 : EPO;
+  CTSEG_REQUIRE(d->Cn_store >= d->Cn && d->Cn_store % EPOv == 0 && (d->out2 ? d->out2_col0 : d->Cn_store) <= d->o_ld,
                 "conv_igemm: Cn_store %d", d->Cn_store);
-  CTSEG_REQUIRE(d->o_ld % EPO == 0 && ((uintptr_t)d->out % 16) == 0, "conv_igemm: out not 16-byte chunked");
+  CTSEG_REQUIRE(d->o_ld % EPOv == 0 && ((uintptr_t)d->out % 16) == 0, "conv_igemm: out not 16-byte chunked");
   const bool smallc = (d->Cg % EPC) != 0 || (d->g_ld % EPC) != 0 || ((uintptr_t)d->in % 16) != 0;
-  CTSEG_REQUIRE(d->g_ld >= d->Cg, "conv_igemm: g_ld < Cg");
+  CTSEG_REQUIRE(d->g_ld >= d->Cg || n_in, "conv_igemm: g_ld < Cg");
   if (d->add) {
     const int ASZ = d->add_f32 ? 4 : SZ;
-    CTSEG_REQUIRE((d->add_ld * ASZ) % (EPO * ASZ) == 0 && ((uintptr_t)d->add % (EPO * ASZ)) == 0 && d->add_ld >= d->Cn_store,
+    const int EPA = n_add ? 4 : EPO;
+    CTSEG_REQUIRE((d->add_ld * ASZ) % (EPA * ASZ) == 0 && ((uintptr_t)d->add % (EPO * ASZ)) == 0 && d->add_ld >= d->Cn_store,
                   "conv_igemm: addend layout");
   }
   CTSEG_REQUIRE((int64_t)d->Xr * d->Yr * d->Zr < (1ll << 31), "conv_igemm: row grid too large");
@@ -375,6 +382,8 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
     CTSEG_REQUIRE(d->stats_tile0 + tiles * d->nclass <= d->stats_tiles && d->stats_ld >= ((d->Cn + bn - 1) / bn) * bn,
                   "conv_igemm: stats partial layout (need stats_ld >= roundup(Cn, tile cols))");
   }
+  if (n_out || n_in || n_add)
+    CTSEG_REQUIRE(halo || (up && !n_in), "conv_igemm: 12-wide bf16 rows are moved by the LDS-halo passes only (ask ctseg_conv_narrow_ok)");
   if (d->out2 != nullptr)
     CTSEG_REQUIRE((stem || down) && d->add == nullptr && d->out2_col0 > 0 && d->out2_col0 % 4 == 0 && d->out2_col0 < d->Cn_store &&
                       d->o2_ld >= d->Cn_store - d->out2_col0 && d->o2_ld % 4 == 0 && ((uintptr_t)d->out2 % 16) == 0,
@@ -408,6 +417,18 @@ extern "C" int ctseg_conv_split_ok(const ctseg_conv_desc* d) {
   if (conv_stem_eligible(a, d->dtype, d->nclass)) return 1;
   if (conv_halo_sw_eligible(a, d->dtype, d->nclass)) return 0;
   return conv_down_halo_eligible(a, d->dtype, d->nclass) ? 1 : 0;
+}
+
+// 1 when this pass may read / write 12-wide bf16 rows (g_ld, o_ld / Cn_store, add_ld of the descriptor): it is taken by
+// the resident-weight LDS-halo kernel (any of them narrow) or by the stride-2 "up" kernel (narrow output / addend only)
+extern "C" int ctseg_conv_narrow_ok(const ctseg_conv_desc* d) {
+  if (d == nullptr || d->dtype != CTSEG_BF16 || d->nclass < 1) return 0;
+  ConvKArgs a;
+  fill_args(d, a);
+  a.out_f32 = d->out_f32; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo; a.add = (const char*)d->add; a.o_ld = d->o_ld;
+  if (conv_halo_eligible(a, d->dtype, d->nclass)) return 1;
+  if (d->g_ld % 8 != 0) return 0;
+  return conv_up_eligible(a, d->dtype, d->nclass) ? 1 : 0;
 }
 
 // tiles per sample (all classes) a pass with this geometry writes InstanceNorm partials for

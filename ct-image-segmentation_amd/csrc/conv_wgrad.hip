@@ -356,16 +356,20 @@ extern "C" int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d) {
   return d->N * d->splits;
 }
 
+extern "C" int ctseg_wgrad_narrow_ok(const ctseg_wgrad_desc* d) { return (d != nullptr && wgrad_halo_eligible(d)) ? 1 : 0; }
+
 extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
   CTSEG_REQUIRE(d != nullptr && d->in && d->dy && d->ws, "conv_wgrad: null pointer");
   CTSEG_REQUIRE(d->dtype == CTSEG_F32 || d->dtype == CTSEG_BF16, "conv_wgrad: bad dtype");
   const int SZ = d->dtype == CTSEG_F32 ? 4 : 2, EPC = 16 / SZ;
-  CTSEG_REQUIRE(d->d_ld % EPC == 0 && ((uintptr_t)d->dy % 16) == 0, "conv_wgrad: dy must be 16-byte chunked");
+  const bool halo = wgrad_halo_eligible(d);     // also moves 12-wide bf16 rows (ctseg_wgrad_narrow_ok)
+  CTSEG_REQUIRE((d->d_ld % EPC == 0 || halo) && ((uintptr_t)d->dy % 16) == 0, "conv_wgrad: dy must be 16-byte chunked");
+  CTSEG_REQUIRE(halo || d->dtype != CTSEG_BF16 || d->g_ld != 12 || d->Cg != 16, "conv_wgrad: 12-wide rows need the LDS-halo kernel");
   const bool smallc = (d->Cg % EPC) != 0 || (d->g_ld % EPC) != 0 || ((uintptr_t)d->in % 16) != 0;
   CTSEG_REQUIRE(d->ntaps >= 1 && d->ntaps <= CTSEG_MAX_TAPS && d->splits >= 1, "conv_wgrad: ntaps/splits");
   const int bnw = ctseg_wgrad_tile_cols(d->Cn);
   const int ktot = d->ntaps * d->Cg;
-  if (wgrad_halo_eligible(d)) {
+  if (halo) {
     CTSEG_REQUIRE(d->kpad_w >= ktot + 16 && d->cn_pad >= ((d->Cn + 15) / 16) * 16, "conv_wgrad: slab too small for the halo kernel");
     launch_wgrad_halo(d, (hipStream_t)stream);
     CTSEG_LAUNCH_CHECK("conv_wgrad_halo");

@@ -63,6 +63,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
     gd_lds[j] = (c >> 1) * (WH_TV * 32) + tv * 32 + (c & 1) * 16;
   }
   u32x4 rx[JX], rd[JD];
+  // 12-wide bf16 rows (24 bytes): chunk 1 is channels 8..11 + zero fill (32-byte planes only)
+  const bool x12 = VB == 32 && (P.g_ld & 7) != 0, d12 = DBY == 32 && (P.d_ld & 7) != 0;
+  auto load_row_chunk = [](const char* p, bool w12, bool second) -> u32x4 {
+    if (!w12) return *reinterpret_cast<const u32x4*>(p);
+    return load_row12_chunk(p, second);
+  };
   auto origin = [&](int t, int& n, int& x0, int& y0, int& z0) {
     n = t / P.tiles;
     int r = t - n * P.tiles;
@@ -81,14 +87,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
       const int xi = x0 - 1 + (gx_hxyz[j] & 0xff), yi = y0 - 1 + ((gx_hxyz[j] >> 8) & 0xff), zi = z0 - 1 + (gx_hxyz[j] >> 16);
       u32x4 v = {0u, 0u, 0u, 0u};
       if ((unsigned)xi < (unsigned)P.X && (unsigned)yi < (unsigned)P.Y && (unsigned)zi < (unsigned)P.Z)
-        v = *reinterpret_cast<const u32x4*>(xb + gx_byte[j]);
+        v = load_row_chunk(xb + gx_byte[j], x12, (gx_lds[j] & 16) != 0);
       rx[j] = v;
     }
 #pragma unroll
     for (int j = 0; j < JD; ++j) {
       const int xi = x0 + (gd_xyz[j] & 0xff), yi = y0 + ((gd_xyz[j] >> 8) & 0xff), zi = z0 + (gd_xyz[j] >> 16);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (xi < P.X && yi < P.Y && zi < P.Z) v = *reinterpret_cast<const u32x4*>(db + gd_byte[j]);
+      if (xi < P.X && yi < P.Y && zi < P.Z) v = load_row_chunk(db + gd_byte[j], d12, (gd_lds[j] & 16) != 0);
       rd[j] = v;
     }
   };
@@ -217,7 +223,10 @@ bool wgrad_halo_eligible(const ctseg_wgrad_desc* d) {
   const int vb = d->Cg * 2, db = ((d->Cn + 15) / 16) * 32;
   if (!(vb == 32 || vb == 64) || !(db == 32 || db == 64)) return false;
   if (d->Xr != d->Xi || d->Yr != d->Yi || d->Zr != d->Zi || d->Zr < 4) return false;
-  if (d->g_ld % 8 || d->d_ld % 8 || d->d_ld < db / 2 || ((uintptr_t)d->in % 16) || ((uintptr_t)d->dy % 16)) return false;
+  // rows 16-byte chunked, or 12 wide (24 bytes) on a 32-byte-plane operand
+  const bool x_ok = d->g_ld % 8 == 0 || (vb == 32 && d->g_ld == 12), d_ok = d->d_ld % 8 == 0 || (db == 32 && d->d_ld == 12);
+  if (!x_ok || !d_ok || d->d_ld < d->Cn || ((uintptr_t)d->in % 16) || ((uintptr_t)d->dy % 16)) return false;
+  if (d->d_ld % 8 == 0 && d->d_ld < db / 2) return false;
   if (d->cn_pad < db / 2) return false;
   if ((int64_t)d->Xi * d->Yi * d->Zi * (d->g_ld > d->d_ld ? d->g_ld : d->d_ld) * 2 >= (1ll << 31)) return false;  // 32-bit per-sample byte offsets
   for (int j = 0; j < 27; ++j)

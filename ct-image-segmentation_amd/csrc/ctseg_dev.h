@@ -51,6 +51,36 @@ template <> __device__ __forceinline__ void store_chunk<BF16>(char* p, const flo
   *reinterpret_cast<u32x4*>(p) = t;
 }
 
+// EP consecutive elements as floats: EP = EPC<T> (one 16-byte chunk) or, for bf16 rows whose stride is an odd multiple of
+// 4 elements (10 classes stored 12 wide: 24-byte rows), EP = 4 (an 8-byte chunk; rows are then only 8-byte aligned)
+template <typename T, int EP> __device__ __forceinline__ void load_ep(const char* p, float* v) {
+  if constexpr (EP == TT<T>::EPC) {
+    load_chunk<T>(p, v);
+  } else {
+    static_assert(EP == 4 && TT<T>::SZ == 2, "half chunks exist for bf16 only");
+    const u32x2 t = *reinterpret_cast<const u32x2*>(p);
+    v[0] = bf2f(t[0] & 0xffffu); v[1] = bf2f(t[0] >> 16); v[2] = bf2f(t[1] & 0xffffu); v[3] = bf2f(t[1] >> 16);
+  }
+}
+template <typename T, int EP> __device__ __forceinline__ void store_ep(char* p, const float* v) {
+  if constexpr (EP == TT<T>::EPC) {
+    store_chunk<T>(p, v);
+  } else {
+    static_assert(EP == 4 && TT<T>::SZ == 2, "half chunks exist for bf16 only");
+    *reinterpret_cast<u32x2*>(p) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+  }
+}
+
+// 16-byte chunk `second` (0 / 1) of a 12-wide bf16 row (24 bytes, 8-byte aligned) as 8-byte pieces: chunk 0 is two of
+// them, chunk 1 is channels 8..11 + zero fill.  (One 16-byte load from the 8-byte aligned address measured 1.4x slower on
+// the whole pass: the memory pipeline splits it.)
+__device__ __forceinline__ u32x4 load_row12_chunk(const char* p, bool second) {
+  const u32x2 lo = *reinterpret_cast<const u32x2*>(p);
+  u32x2 hi = {0u, 0u};
+  if (!second) hi = *reinterpret_cast<const u32x2*>(p + 8);
+  return u32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // n consecutive elements of runtime dtype -> floats (n = 4 or 8; pointer aligned to n*size)
 __device__ __forceinline__ void load_n_as_float(const char* p, bool is_f32, int n, float* v) {
   if (is_f32) {

@@ -185,9 +185,18 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
         for (int c = 0; c < CP; ++c) d[c] = (c < C) ? ce_scale * (pr[c] - ((c == t) ? 1.f : 0.f)) : 0.f;
       }
       char* gp = dlogits + vox * g_ld * GSZ;
+      if (GSZ == 2 && (g_ld & 7) != 0) {
+        // bf16 rows 12 wide (24 bytes, 8-byte aligned): 8-byte pieces
+        if constexpr (GSZ == 2) {
 #pragma unroll
-      for (int q = 0; q < CMAX / GEPC; ++q)
-        if (q * GEPC < g_ld) store_chunk<GT>(gp + q * 16, d + q * GEPC);
+          for (int u = 0; u < CP / 4; ++u)
+            if (u * 4 < g_ld) store_ep<GT, 4>(gp + u * 8, d + u * 4);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < CMAX / GEPC; ++q)
+          if (q * GEPC < g_ld) store_chunk<GT>(gp + q * 16, d + q * GEPC);
+      }
     }
   }
 
@@ -373,8 +382,10 @@ extern "C" int ctseg_seg_loss(const float* logits, int32_t ld, const uint8_t* la
   CTSEG_REQUIRE(P > 0 && (!do_stats || (part && cnt)), "seg_loss: stats buffers");
   if (do_grad) {
     CTSEG_REQUIRE(coef && dlogits && (gdtype == CTSEG_F32 || gdtype == CTSEG_BF16), "seg_loss: grad buffers");
-    const int gepc = gdtype == CTSEG_F32 ? 4 : 8;
-    CTSEG_REQUIRE(g_ld % gepc == 0 && g_ld >= C && g_ld <= CMAX && ((uintptr_t)dlogits % 16) == 0, "seg_loss: dlogits stride %d", g_ld);
+    // bf16 gradients: 16-byte chunked rows, or 12 wide (8-byte pieces) for the <= 12 class case
+    CTSEG_REQUIRE(g_ld % 4 == 0 && (gdtype == CTSEG_F32 || g_ld % 8 == 0 || g_ld == 12) && g_ld >= C && g_ld <= CMAX &&
+                      ((uintptr_t)dlogits % 16) == 0,
+                  "seg_loss: dlogits stride %d", g_ld);
   }
   hipStream_t st = (hipStream_t)stream;
   const bool lite = (do_stats == 2 || do_stats == 0) && (do_grad == 2 || do_grad == 0);   // cross-entropy only

@@ -47,13 +47,13 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
   if (threadIdx.x == 0) counter[n] = 0u;
 }
 
-template <typename T>
+template <typename T, int EPC>
 __global__ __launch_bounds__(256) void instnorm_prelu_fwd_kernel(const char* __restrict__ y, int y_ld,
                                                                   const float* __restrict__ mean_rstd,
                                                                   const float* __restrict__ alpha, const char* __restrict__ res,
                                                                   int res_ld, char* __restrict__ out, int out_ld, int64_t S,
                                                                   int C, int Cv) {
-  constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
+  constexpr int SZ = TT<T>::SZ;   // EPC: elements per chunk (a row is Cv chunks of EPC elements)
   extern __shared__ float s_mr[];  // [C][2]
   const int n = blockIdx.y;
   if (mean_rstd != nullptr)
@@ -61,13 +61,11 @@ __global__ __launch_bounds__(256) void instnorm_prelu_fwd_kernel(const char* __r
   __syncthreads();
   const float al = alpha != nullptr ? alpha[0] : 1.f;
   const int64_t total = S * Cv;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t v = i / Cv;
-    const int cv = (int)(i - v * Cv);
+  auto body = [&](int64_t v, int cv) {
     const int64_t vox = (int64_t)n * S + v;
     float x[EPC], r[EPC];
-    load_chunk<T>(y + (vox * y_ld + cv * EPC) * SZ, x);
-    if (res != nullptr) load_chunk<T>(res + (vox * res_ld + cv * EPC) * SZ, r);
+    load_ep<T, EPC>(y + (vox * y_ld + cv * EPC) * SZ, x);
+    if (res != nullptr) load_ep<T, EPC>(res + (vox * res_ld + cv * EPC) * SZ, r);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       const int c = cv * EPC + e;
@@ -82,19 +80,33 @@ __global__ __launch_bounds__(256) void instnorm_prelu_fwd_kernel(const char* __r
       }
       x[e] = o;
     }
-    store_chunk<T>(out + (vox * out_ld + cv * EPC) * SZ, x);
+    store_ep<T, EPC>(out + (vox * out_ld + cv * EPC) * SZ, x);
+  };
+  // a thread keeps its channel chunk when the grid stride is a multiple of Cv (the launcher arranges it): no 64-bit
+  // division per element, and the per-channel constants stay in registers
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (stride % Cv == 0) {
+    int64_t v = i0 / Cv;
+    const int cv = (int)(i0 - v * Cv);
+    const int64_t vstep = stride / Cv;
+    for (; v < S; v += vstep) body(v, cv);
+  } else {
+    for (int64_t i = i0; i < total; i += stride) {
+      const int64_t v = i / Cv;
+      body(v, (int)(i - v * Cv));
+    }
   }
 }
 
 // backward pass 1: per block (p, n): rows [p*rows_per, ...) of sample n -> partials[n][p][3][ld]
-template <typename T>
+template <typename T, int EPC>
 __global__ __launch_bounds__(256) void instnorm_prelu_bwd_reduce_kernel(const char* __restrict__ g, int g_ld,
                                                                          const char* __restrict__ y, int y_ld,
                                                                          const float* __restrict__ mean_rstd,
                                                                          const float* __restrict__ alpha,
                                                                          float* __restrict__ partials, int P, int ld, int64_t S,
                                                                          int C, int Cv) {
-  constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
+  constexpr int SZ = TT<T>::SZ;   // EPC: elements per chunk (a row is Cv chunks of EPC elements)
   __shared__ float s_red[256 * 3 * EPC];
   extern __shared__ float s_mr[];
   const int p = blockIdx.x, n = blockIdx.y;
@@ -112,8 +124,8 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_reduce_kernel(const ch
     for (int64_t v = v0 + rsub; v < v1; v += nrow_thr) {
       const int64_t vox = (int64_t)n * S + v;
       float gv[EPC], yv[EPC];
-      load_chunk<T>(g + (vox * g_ld + cv * EPC) * SZ, gv);
-      load_chunk<T>(y + (vox * y_ld + cv * EPC) * SZ, yv);
+      load_ep<T, EPC>(g + (vox * g_ld + cv * EPC) * SZ, gv);
+      load_ep<T, EPC>(y + (vox * y_ld + cv * EPC) * SZ, yv);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         const int c = cv * EPC + e;
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_dalpha_kernel(const double
 // COLSUM: also emit per-block column sums of dy (fp32, before storage rounding) -> cs_part[(n*gridDim.x + block)][pld]; the
 // launcher picks gridDim.x so that a thread's channel chunk is the same in every grid-stride iteration.  This is the bias
 // gradient of the ConvTranspose3d that feeds this norm (its dOut = dy), which used to cost a separate pass over dy.
-template <typename T, bool COLSUM>
+template <typename T, int EPC, bool COLSUM>
 __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const char* __restrict__ g, int g_ld,
                                                                         const char* __restrict__ y, int y_ld,
                                                                         const float* __restrict__ mean_rstd,
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
                                                                         int dy_ld, char* __restrict__ g_copy, int g_copy_ld,
                                                                         int64_t S, int C, int Cv, float* __restrict__ cs_part,
                                                                         int pld) {
-  constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
+  constexpr int SZ = TT<T>::SZ;   // EPC: elements per chunk (a row is Cv chunks of EPC elements)
   extern __shared__ float s_tab[];  // [C][4]: mean, rstd, s1, s2  (+ [256][EPC] column-sum scratch when COLSUM)
   float cs[EPC];
 #pragma unroll
@@ -212,14 +224,11 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
   __syncthreads();
   const float al = alpha[0];
   const int64_t total = S * Cv;
-  for (int64_t ir = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ir < total; ir += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = total - 1 - ir;
-    const int64_t v = i / Cv;
-    const int cv = (int)(i - v * Cv);
+  auto body = [&](int64_t v, int cv) {
     const int64_t vox = (int64_t)n * S + v;
     float gv[EPC], yv[EPC], o[EPC];
-    load_chunk<T>(g + (vox * g_ld + cv * EPC) * SZ, gv);
-    load_chunk<T>(y + (vox * y_ld + cv * EPC) * SZ, yv);
+    load_ep<T, EPC>(g + (vox * g_ld + cv * EPC) * SZ, gv);
+    load_ep<T, EPC>(y + (vox * y_ld + cv * EPC) * SZ, yv);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       const int c = cv * EPC + e;
@@ -233,8 +242,38 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
       o[e] = r;
       if (COLSUM) cs[e] += r;
     }
-    store_chunk<T>(dy + (vox * dy_ld + cv * EPC) * SZ, o);
-    if (g_copy != nullptr) store_chunk<T>(g_copy + (vox * g_copy_ld + cv * EPC) * SZ, gv);
+    bool whole_row = false;
+    if constexpr (EPC * SZ == 8) whole_row = cv == Cv - 1 && dy_ld == (Cv + 1) * EPC;
+    if constexpr (EPC * SZ == 8) {
+      if (whole_row) {
+      // 8-byte chunks into rows one chunk wider than the channels (12-wide inputs, 16-wide dy): the last chunk and the
+      // padding go out as ONE 16-byte store, so every 32-byte row is written whole (no partial sectors at the memory side)
+      float o2[2 * EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { o2[e] = o[e]; o2[EPC + e] = 0.f; }
+        store_ep<T, 2 * EPC>(dy + (vox * dy_ld + cv * EPC) * SZ, o2);
+      }
+    }
+    if (!whole_row) store_ep<T, EPC>(dy + (vox * dy_ld + cv * EPC) * SZ, o);
+    if (g_copy != nullptr) store_ep<T, EPC>(g_copy + (vox * g_copy_ld + cv * EPC) * SZ, gv);
+  };
+  {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, ir0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (stride % Cv == 0) {       // fixed channel chunk per thread: no 64-bit division per element
+      if (ir0 < total) {
+        const int64_t i = total - 1 - ir0;
+        int64_t v = i / Cv;
+        const int cv = (int)(i - v * Cv);
+        const int64_t vstep = stride / Cv;
+        for (; v >= 0; v -= vstep) body(v, cv);
+      }
+    } else {
+      for (int64_t ir = ir0; ir < total; ir += stride) {
+        const int64_t i = total - 1 - ir;
+        const int64_t v = i / Cv;
+        body(v, (int)(i - v * Cv));
+      }
+    }
   }
   if constexpr (COLSUM) {
     // (gridDim.x * 256) % Cv == 0: thread t handled the same chunk column in every iteration (the sweep runs backwards from
@@ -326,19 +365,35 @@ static inline int ew_blocks(int64_t total) {
   int64_t b = (total + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
+// grid whose stride (blocks * 256) is a multiple of Cv, so that a thread keeps one channel chunk (256 supplies the twos)
+static inline int ew_blocks_for(int64_t total, int Cv) {
+  int b = ew_blocks(total), step = Cv;
+  while (step % 2 == 0) step /= 2;
+  if (b >= step) b = b / step * step;
+  return b;
+}
 
 }  // namespace ctseg
 
 using namespace ctseg;
 
-#define CHECK_CL(dtype, C, ...)                                                                            \
+// EPC_ = elements per chunk the launch works in: 16-byte chunks, or 8-byte ones for bf16 when some tensor's channel stride
+// is a multiple of 4 but not of 8 (10 classes stored 12 wide); every stride must then be a multiple of 4
+#define CHECK_CL_(dtype, C, ALLOW_HALF, ...)                                                               \
   CTSEG_REQUIRE(dtype == CTSEG_F32 || dtype == CTSEG_BF16, "bad dtype");                                   \
-  const int EPC_ = dtype == CTSEG_F32 ? 4 : 8;                                                             \
+  int EPC_ = dtype == CTSEG_F32 ? 4 : 8;                                                                   \
+  {                                                                                                        \
+    const int lds_[] = {__VA_ARGS__};                                                                      \
+    if (ALLOW_HALF && dtype == CTSEG_BF16)                                                                 \
+      for (int ld_ : lds_) if (ld_ % 8 != 0) EPC_ = 4;                                                     \
+  }                                                                                                        \
   const int Cv = (C + EPC_ - 1) / EPC_;                                                                    \
   {                                                                                                        \
     const int lds_[] = {__VA_ARGS__};                                                                      \
     for (int ld_ : lds_) CTSEG_REQUIRE(ld_ % EPC_ == 0 && ld_ >= Cv * EPC_, "channel stride %d not chunked for C=%d", ld_, C); \
   }
+#define CHECK_CL(dtype, C, ...) CHECK_CL_(dtype, C, false, __VA_ARGS__)
+#define CHECK_CL_HALF(dtype, C, ...) CHECK_CL_(dtype, C, true, __VA_ARGS__)
 
 extern "C" int ctseg_instnorm_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t col0, int32_t C,
                                        double count, double eps, double* scratch, float* mean_rstd, void* stream) {
@@ -357,17 +412,18 @@ extern "C" int ctseg_instnorm_prelu_fwd(int32_t dtype, const void* y, int32_t y_
                                         const void* res, int32_t res_ld, void* out, int32_t out_ld, int32_t N, int64_t S,
                                         int32_t C, void* stream) {
   CTSEG_REQUIRE(y && out && N > 0 && S > 0 && C > 0, "instnorm_prelu_fwd: bad arguments");
-  CHECK_CL(dtype, C, y_ld, out_ld, res ? res_ld : y_ld);
+  CHECK_CL_HALF(dtype, C, y_ld, out_ld, res ? res_ld : y_ld);
   CTSEG_REQUIRE(mean_rstd == nullptr || alpha != nullptr, "instnorm_prelu_fwd: alpha missing");
-  dim3 grid(ew_blocks(S * Cv), N);
+  dim3 grid(ew_blocks_for(S * Cv, Cv), N);
   const size_t sh = 2 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CTSEG_F32)
-    hipLaunchKernelGGL(instnorm_prelu_fwd_kernel<float>, grid, dim3(256), sh, st, (const char*)y, y_ld, mean_rstd, alpha,
-                       (const char*)res, res_ld, (char*)out, out_ld, S, C, Cv);
-  else
-    hipLaunchKernelGGL(instnorm_prelu_fwd_kernel<BF16>, grid, dim3(256), sh, st, (const char*)y, y_ld, mean_rstd, alpha,
-                       (const char*)res, res_ld, (char*)out, out_ld, S, C, Cv);
+#define CTSEG_FWD(T, EP)                                                                                                      \
+  hipLaunchKernelGGL((instnorm_prelu_fwd_kernel<T, EP>), grid, dim3(256), sh, st, (const char*)y, y_ld, mean_rstd, alpha,     \
+                     (const char*)res, res_ld, (char*)out, out_ld, S, C, Cv)
+  if (dtype == CTSEG_F32) CTSEG_FWD(float, 4);
+  else if (EPC_ == 8) CTSEG_FWD(BF16, 8);
+  else CTSEG_FWD(BF16, 4);
+#undef CTSEG_FWD
   CTSEG_LAUNCH_CHECK("instnorm_prelu_fwd");
   return 0;
 }
@@ -376,16 +432,17 @@ extern "C" int ctseg_instnorm_prelu_bwd_reduce(int32_t dtype, const void* g, int
                                                const float* mean_rstd, const float* alpha, float* partials, int32_t P,
                                                int32_t ld, int32_t N, int64_t S, int32_t C, void* stream) {
   CTSEG_REQUIRE(g && y && mean_rstd && alpha && partials && P > 0 && N > 0 && C <= ld, "instnorm_prelu_bwd_reduce: bad arguments");
-  CHECK_CL(dtype, C, g_ld, y_ld);
+  CHECK_CL_HALF(dtype, C, g_ld, y_ld);
   CTSEG_REQUIRE(Cv <= 256, "instnorm_prelu_bwd_reduce: too many channels");
   const size_t sh = 2 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CTSEG_F32)
-    hipLaunchKernelGGL(instnorm_prelu_bwd_reduce_kernel<float>, dim3(P, N), dim3(256), sh, st, (const char*)g, g_ld,
-                       (const char*)y, y_ld, mean_rstd, alpha, partials, P, ld, S, C, Cv);
-  else
-    hipLaunchKernelGGL(instnorm_prelu_bwd_reduce_kernel<BF16>, dim3(P, N), dim3(256), sh, st, (const char*)g, g_ld,
-                       (const char*)y, y_ld, mean_rstd, alpha, partials, P, ld, S, C, Cv);
+#define CTSEG_RED(T, EP)                                                                                                     \
+  hipLaunchKernelGGL((instnorm_prelu_bwd_reduce_kernel<T, EP>), dim3(P, N), dim3(256), sh, st, (const char*)g, g_ld,         \
+                     (const char*)y, y_ld, mean_rstd, alpha, partials, P, ld, S, C, Cv)
+  if (dtype == CTSEG_F32) CTSEG_RED(float, 4);
+  else if (EPC_ == 8) CTSEG_RED(BF16, 8);
+  else CTSEG_RED(BF16, 4);
+#undef CTSEG_RED
   CTSEG_LAUNCH_CHECK("instnorm_prelu_bwd_reduce");
   return 0;
 }
@@ -411,8 +468,8 @@ static int bwd_apply_launch(int32_t dtype, const void* g, int32_t g_ld, const vo
                             const float* alpha, const float* sums, void* dy, int32_t dy_ld, void* g_copy, int32_t g_copy_ld, int32_t N,
                             int64_t S, int32_t C, float* cs_part, int32_t P_cap, float* cs_out, void* stream) {
   CTSEG_REQUIRE(g && y && mean_rstd && alpha && sums && dy && N > 0, "instnorm_prelu_bwd_apply: bad arguments");
-  CHECK_CL(dtype, C, g_ld, y_ld, dy_ld, g_copy ? g_copy_ld : dy_ld);
-  int gx = ew_blocks(S * Cv);
+  CHECK_CL_HALF(dtype, C, g_ld, y_ld, dy_ld, g_copy ? g_copy_ld : dy_ld);
+  int gx = ew_blocks_for(S * Cv, Cv);
   const bool colsum = cs_part != nullptr;
   const int pld = Cv * EPC_;
   if (colsum) {
@@ -427,11 +484,12 @@ static int bwd_apply_launch(int32_t dtype, const void* g, int32_t g_ld, const vo
   dim3 grid(gx, N);
   const size_t sh = (4 * C + (colsum ? 256 * EPC_ : 0)) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define CTSEG_APPLY(T, CS)                                                                                                      \
-  hipLaunchKernelGGL((instnorm_prelu_bwd_apply_kernel<T, CS>), grid, dim3(256), sh, st, (const char*)g, g_ld, (const char*)y, y_ld, \
+#define CTSEG_APPLY(T, EP, CS)                                                                                                      \
+  hipLaunchKernelGGL((instnorm_prelu_bwd_apply_kernel<T, EP, CS>), grid, dim3(256), sh, st, (const char*)g, g_ld, (const char*)y, y_ld, \
                      mean_rstd, alpha, sums, (char*)dy, dy_ld, (char*)g_copy, g_copy_ld, S, C, Cv, cs_part, pld)
-  if (dtype == CTSEG_F32) { if (colsum) CTSEG_APPLY(float, true); else CTSEG_APPLY(float, false); }
-  else { if (colsum) CTSEG_APPLY(BF16, true); else CTSEG_APPLY(BF16, false); }
+  if (dtype == CTSEG_F32) { if (colsum) CTSEG_APPLY(float, 4, true); else CTSEG_APPLY(float, 4, false); }
+  else if (EPC_ == 8) { if (colsum) CTSEG_APPLY(BF16, 8, true); else CTSEG_APPLY(BF16, 8, false); }
+  else { if (colsum) CTSEG_APPLY(BF16, 4, true); else CTSEG_APPLY(BF16, 4, false); }
 #undef CTSEG_APPLY
   if (colsum) hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(1024), 0, st, cs_part, gx * N, pld, C, cs_out);
   CTSEG_LAUNCH_CHECK("instnorm_prelu_bwd_apply");

@@ -81,6 +81,13 @@ int ctseg_conv_tile_cols(int32_t Cn);
 int ctseg_conv_num_tiles(const ctseg_conv_desc* d);
 /* 1 if a pass with this geometry can take out2 / out2_col0 / o2_ld (out2_col0 must be set; pointers are ignored) */
 int ctseg_conv_split_ok(const ctseg_conv_desc* d);
+/* Narrow rows.  A bf16 tensor of 9..12 channels (the reference's 10 classes) may be stored 12 elements wide (24-byte rows)
+ * instead of 16: the tensors either side of the logits convolution are the largest the network moves, and a quarter of
+ * their bytes is padding.  g_ld == 12 with Cg == 16 (channels 12..15 read as zero), o_ld == 12 with Cn_store == 12 and
+ * add_ld == 12 are accepted where this returns 1: the resident-weight 3x3x3 LDS-halo pass (any of the three) and the
+ * stride-2 transposed "up" pass (output / addend only).  The InstanceNorm, loss and layout entry points take such rows as
+ * they are.  The host mirror asks before it lays a tensor out this way and falls back to 16-wide rows otherwise. */
+int ctseg_conv_narrow_ok(const ctseg_conv_desc* d);
 int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream);
 
 /* Weight gradient: R[tap*Cg+a][b] = sum_rows in[row*sin+d(tap)][a] * dy[row][b]; row K=ntaps*Cg of R is
@@ -104,6 +111,8 @@ int ctseg_wgrad_tile_cols(int32_t Cn);
 /* slabs this descriptor makes ctseg_conv_wgrad write (N*splits, or one per persistent workgroup of the LDS-halo
  * kernel that few-channel 3x3x3 stride-1 bf16 layers take): size `ws` and call the reduce with it. `ws`/`dy`/`in` may be NULL here */
 int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d);
+/* 1 when this weight-gradient pass may read 12-wide bf16 rows (g_ld == 12 with Cg == 16 and / or d_ld == 12): the LDS-halo kernel */
+int ctseg_wgrad_narrow_ok(const ctseg_wgrad_desc* d);
 int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream);
 /* dw[(b*A + a)*T + t] = sum_s ws[s][t*Astride + a][col0 + b]  for a < A, b < nb;
  * db[b] = sum_s ws[s][T*Astride][col0+b] (db may be NULL).  Astride = the pass's (padded) Cg. */

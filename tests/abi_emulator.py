@@ -359,7 +359,7 @@ def patch_native(nat, emu):
     orig_req = nat.require_gpu
     nat.require_gpu = lambda t, what: None
     orig_query = nat.query
-    own = {"ctseg_conv_split_ok": emu.conv_split_ok}
+    own = {"ctseg_conv_split_ok": emu.conv_split_ok, "ctseg_conv_narrow_ok": lambda d: 0, "ctseg_wgrad_narrow_ok": lambda d: 0}
     nat.query = lambda name, d: own[name](d) if name in own else orig_query(name, d)
 
     def undo():

@@ -560,3 +560,43 @@ def test_rccl_gradient_exchange_on_one_rank_matches_plain_step(monkeypatch):
         assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
     finally:
         dist.destroy_process_group()
+
+
+def test_narrow_rows_change_no_forward_bit_and_no_gradient_beyond_sum_order(monkeypatch):
+    """bf16 tensors either side of the 10-class logits convolution are laid out 12 wide (24-byte rows) when every pass that
+    touches them can move such rows.  The layout changes no arithmetic of the forward pass (logits bit-identical to the
+    16-wide plan); the backward differs only in the order of the fp32 InstanceNorm-backward partial sums."""
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    g = torch.Generator().manual_seed(21)
+    images = torch.randn(2, 1, 32, 48, 16, generator=g).to(DEV)
+    masks = (torch.rand(2, 9, 32, 48, 16, generator=g) < 0.1).to(torch.uint8).to(DEV)
+    ind = torch.ones(2, 9, dtype=torch.float64).to(DEV)
+    out = {}
+    for narrow in ("1", "0"):
+        monkeypatch.setenv("CTSEG_NARROW_ROWS", narrow)
+        torch.manual_seed(5)
+        m = BaseUNet3D(filters=[16, 32, 64], loss_fx=["CrossEntropy"], precision="bf16").to(DEV)
+        loss = float(m.fit_step((images, masks, ind)))
+        eng = m.unet.engine()
+        plan = eng.last_plan
+        assert plan.dlogits.ld == (12 if narrow == "1" else 16), "the 32x48x16 head is eligible for 12-wide rows"
+        torch.cuda.synchronize()
+        out[narrow] = (loss, eng.logits_view(plan).clone(), eng.store.flat_g.clone())
+    assert out["1"][0] == out["0"][0]
+    assert torch.equal(out["1"][1], out["0"][1])
+    ga, gb = out["1"][2], out["0"][2]
+    assert float((ga - gb).abs().max()) <= 2e-3 * float(gb.abs().max())
+
+
+def test_narrow_rows_fall_back_where_a_pass_cannot_move_them(monkeypatch):
+    """depth 2 (< 4 voxels): the logits convolution does not take the LDS-halo kernel -> the plan is recorded 16 wide"""
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    monkeypatch.setenv("CTSEG_NARROW_ROWS", "1")
+    g = torch.Generator().manual_seed(22)
+    images = torch.randn(1, 1, 16, 16, 2, generator=g).to(DEV)
+    masks = (torch.rand(1, 9, 16, 16, 2, generator=g) < 0.1).to(torch.uint8).to(DEV)
+    ind = torch.ones(1, 9, dtype=torch.float64).to(DEV)
+    torch.manual_seed(6)
+    m = BaseUNet3D(filters=[16, 32], loss_fx=["CrossEntropy"], precision="bf16").to(DEV)
+    loss = float(m.fit_step((images, masks, ind)))
+    assert np.isfinite(loss) and m.unet.engine().last_plan.dlogits.ld == 16
