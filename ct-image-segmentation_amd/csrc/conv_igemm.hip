@@ -275,13 +275,19 @@ static int launch_cfg(const ConvKArgs& a, bool smallc, int nclass, hipStream_t s
 // rows of the row grid one workgroup tile covers.  Cn > 128 in bf16 (never fp32 output there): 192 x 256 tile, 8 waves —
 // the 128 x 128 tile is bound by the L2 -> LDS operand traffic per CU (64 FLOP/B); 192 x 256 moves 110 FLOP/B, and the
 // M of every layer of the reference's volumes (48 / 24 / 12 / 6 deep) is a multiple of 192.
-static int tile_rows_for(int Cn, int dtype, int out_f32, bool smallc) {
-  if (Cn > 128 && dtype == CTSEG_BF16 && !out_f32 && !smallc) return 192;
-  return Cn <= 32 ? 256 : 128;
+// 65..128 columns take the 192 x 128 tile of the ring-pipelined kernel where it is eligible (Cg a multiple of 32 ...): 256
+// tiles for the 49152-row layers instead of 384 tiles of 128 rows (1.5 rounds over the 256 CUs).
+static int tile_rows_for(const ConvKArgs& a, int dtype, bool smallc, int nclass) {
+  if (dtype == CTSEG_BF16 && !a.out_f32 && !smallc) {
+    if (a.Cn > 128) return 192;
+    // (not for 32 gathered channels: those passes are operand-traffic bound with short K loops; measured 0.21 -> 0.24 ms)
+    if (a.Cn > 64 && a.Cg >= 64 && conv_ring_eligible(a, dtype, nclass)) return 192;
+  }
+  return a.Cn <= 32 ? 256 : 128;
 }
 
 template <typename T> static int launch_dtype(ConvKArgs& a, bool smallc, int nclass, hipStream_t st) {
-  const int bm = tile_rows_for(a.Cn, TT<T>::DT, a.out_f32, smallc);
+  const int bm = tile_rows_for(a, TT<T>::DT, smallc, nclass);
   a.tiles = (a.rows + bm - 1) / bm;
   if constexpr (TT<T>::DT == CTSEG_BF16) {
     if (bm == 192) {
@@ -376,9 +382,9 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   } else if (d->stats && up) {
     CTSEG_REQUIRE(d->stats_tile0 + conv_up_tiles(a) <= d->stats_tiles && d->stats_ld >= 16, "conv_igemm: stats partial layout (up pass)");
   } else if (d->stats) {
-    const int bm = tile_rows_for(d->Cn, d->dtype, d->out_f32, smallc);
+    const int bm = tile_rows_for(a, d->dtype, smallc, d->nclass);
     const int tiles = halo ? conv_halo_slots(a, d->dtype) : (a.rows + bm - 1) / bm;
-    const int bn = bm == 192 ? 256 : ctseg_conv_tile_cols(d->Cn);
+    const int bn = bm == 192 ? (d->Cn > 128 ? 256 : 128) : ctseg_conv_tile_cols(d->Cn);
     CTSEG_REQUIRE(d->stats_tile0 + tiles * d->nclass <= d->stats_tiles && d->stats_ld >= ((d->Cn + bn - 1) / bn) * bn,
                   "conv_igemm: stats partial layout (need stats_ld >= roundup(Cn, tile cols))");
   }
@@ -445,6 +451,6 @@ extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
   if (conv_down_halo_eligible(a, d->dtype, d->nclass)) return conv_down_halo_slots(a);
   const int SZq = d->dtype == CTSEG_F32 ? 4 : 2, EPCq = 16 / SZq;
   const bool smallq = (d->Cg % EPCq) != 0 || (d->g_ld % EPCq) != 0 || ((uintptr_t)d->in % 16) != 0;
-  const int bm = tile_rows_for(d->Cn, d->dtype, d->out_f32, smallq);
+  const int bm = tile_rows_for(a, d->dtype, smallq, d->nclass);
   return ((a.rows + bm - 1) / bm) * d->nclass;
 }

@@ -26,8 +26,9 @@
 
 namespace ctseg {
 
-struct RingCfg {
-  static constexpr int BM = 192, BN = 256, WGM = 2, WGN = 4, NW = WGM * WGN, NTHR = 64 * NW, D = 5;
+// BN = 256: waves 2 x 4, wave tile 96 x 64.  BN = 128 (passes with 65..128 columns): waves 4 x 2, wave tile 48 x 64.
+template <int BN_> struct RingCfgT {
+  static constexpr int BM = 192, BN = BN_, WGM = BN_ == 256 ? 2 : 4, WGN = BN_ == 256 ? 4 : 2, NW = WGM * WGN, NTHR = 64 * NW, D = 5;
   static constexpr int RB = 64, KS = 32;                 // LDS row bytes / K per stage
   static constexpr int BOFF = BM * RB, STAGE = (BM + BN) * RB;
   static constexpr int CROW = BN * 2 + 16;
@@ -36,6 +37,7 @@ struct RingCfg {
   static constexpr int ROWTAB = BM * 8;
   static constexpr int TOTAL = MAIN + STATS + ROWTAB + 64 * 4;
 };
+using RingCfg = RingCfgT<256>;
 
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t __attribute__((address_space(3)))* lds_u32_ptr;
@@ -55,12 +57,14 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p, uint32_t bytes) {
 }
 
 // NA = 16-row blocks of the gathered operand this wave fetches per stage (12 blocks over 8 waves: 2 for waves 0-3, 1 for 4-7)
-template <int NA>
+template <int BN, int NA>
 __device__ __forceinline__ void ring_main(const ConvKArgs& P, const ctseg_conv_class& K, char* smem, const int* sRow, const int* sTap,
-                                          f32x4 (&acc)[4][6], int n, int col0, int wave, int lane) {
-  using C = RingCfg;
+                                          f32x4 (&acc)[4][RingCfgT<BN>::BM / RingCfgT<BN>::WGM / 16], int n, int col0, int wave,
+                                          int lane) {
+  using C = RingCfgT<BN>;
   constexpr int BM = C::BM, D = C::D, RB = C::RB, STAGE = C::STAGE, BOFF = C::BOFF, NW = C::NW, WGN = C::WGN;
-  constexpr int WTM = BM / C::WGM, WTN = C::BN / WGN, MT = 6, NT = WTN / 16, NB = 16 / NW;
+  constexpr int WTM = BM / C::WGM, WTN = BN / WGN, MT = WTM / 16, NT = WTN / 16, NB = BN / 16 / NW;
+  static_assert(NT == 4 && NB >= 1, "wave tile is 64 columns wide");
   const int wm = wave / WGN, wn = wave % WGN;
   const int r16 = lane & 15, q4 = lane >> 4;
   const int ntaps = K.ntaps, kpad = K.kpad;
@@ -170,9 +174,10 @@ __device__ __forceinline__ void ring_main(const ConvKArgs& P, const ctseg_conv_c
   static_assert(D == 5, "the drain above is written for a five-deep ring");
 }
 
+template <int BN>
 __global__ __launch_bounds__(512) void conv_igemm_ring_kernel(const ConvKArgs P) {
-  using C = RingCfg;
-  constexpr int BM = C::BM, BN = C::BN;
+  using C = RingCfgT<BN>;
+  constexpr int BM = C::BM, MT = BM / C::WGM / 16;
   static_assert(C::TOTAL <= 160 * 1024, "LDS");
 
   __shared__ __attribute__((aligned(16))) char smem[C::TOTAL];
@@ -207,22 +212,22 @@ __global__ __launch_bounds__(512) void conv_igemm_ring_kernel(const ConvKArgs P)
   }
   __syncthreads();
 
-  f32x4 acc[4][6];
+  f32x4 acc[4][MT];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // the two halves of the workgroup run the same schedule with a different (compile-time) number of loads per stage
-  if (wave < 4) ring_main<2>(P, K, smem, sRow, sTap, acc, n, col0, wave, lane);
-  else ring_main<1>(P, K, smem, sRow, sTap, acc, n, col0, wave, lane);
+  if (wave < 4) ring_main<BN, 2>(P, K, smem, sRow, sTap, acc, n, col0, wave, lane);
+  else ring_main<BN, 1>(P, K, smem, sRow, sTap, acc, n, col0, wave, lane);
   __syncthreads();
 
   conv_epilogue<BF16, BM, BN, C::WGM, C::WGN>(P, K, smem, sStats, sRow, acc, n, tile, (int)blockIdx.z, col0);
 }
 
 bool conv_ring_eligible(const ConvKArgs& a, int dtype, int nclass) {
-  if (dtype != CTSEG_BF16 || a.out_f32 || a.Cn <= 128 || a.Cg % 32 != 0) return false;
+  if (dtype != CTSEG_BF16 || a.out_f32 || a.Cn <= 64 || a.Cg % 32 != 0) return false;
   if ((int64_t)a.N * a.Xi * a.Yi * a.Zi * a.g_ld * 2 >= (int64_t)1 << 31) return false;   // 32-bit buffer offsets
   for (int c = 0; c < nclass; ++c)
     if (a.cls[c].kpad % 64 != 0 || a.cls[c].kpad < 256 || a.cls[c].ntaps > 32 || a.cls[c].kpad < a.cls[c].ntaps * a.Cg ||
@@ -232,8 +237,13 @@ bool conv_ring_eligible(const ConvKArgs& a, int dtype, int nclass) {
 }
 
 void launch_conv_ring(const ConvKArgs& a, int nclass, hipStream_t st) {
-  dim3 grid((unsigned)(a.tiles * a.N), (unsigned)((a.Cn + RingCfg::BN - 1) / RingCfg::BN), (unsigned)nclass);
-  hipLaunchKernelGGL(conv_igemm_ring_kernel, grid, dim3(RingCfg::NTHR), 0, st, a);
+  if (a.Cn > 128) {
+    dim3 grid((unsigned)(a.tiles * a.N), (unsigned)((a.Cn + 255) / 256), (unsigned)nclass);
+    hipLaunchKernelGGL(conv_igemm_ring_kernel<256>, grid, dim3(512), 0, st, a);
+  } else {
+    dim3 grid((unsigned)(a.tiles * a.N), 1u, (unsigned)nclass);
+    hipLaunchKernelGGL(conv_igemm_ring_kernel<128>, grid, dim3(512), 0, st, a);
+  }
 }
 
 }  // namespace ctseg

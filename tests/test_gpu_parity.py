@@ -118,12 +118,15 @@ def test_halo_kernels_on_degenerate_extents(kind, cin, cout, shape):
 
 @pytest.mark.parametrize("kind,cin,cout,shape", [("conv", 256, 256, (1, 8, 8, 6)), ("conv", 128, 256, (2, 7, 9, 5)),
                                                  ("conv", 96, 160, (1, 6, 10, 7)), ("conv_s2", 64, 256, (1, 12, 14, 10)),
-                                                 ("convT", 384, 64, (1, 5, 6, 4)), ("conv", 256, 128, (1, 9, 7, 6))])
+                                                 ("convT", 384, 64, (1, 5, 6, 4)), ("conv", 256, 128, (1, 9, 7, 6)),
+                                                 ("conv", 128, 128, (2, 8, 8, 6)), ("conv_s2", 32, 128, (1, 20, 12, 10)),
+                                                 ("conv", 64, 96, (1, 7, 9, 11))])
 def test_ring_pipelined_tile_vs_torch_cpu(kind, cin, cout, shape):
     """passes with > 128 output columns and a multiple of 32 gathered channels (bf16) take conv_igemm_ring_kernel: forward of
     Conv3d n->256 / 96->160 (column tile 5/8 full), input gradient of 256->128 (Cn = 256) and of the stride-2 64->256
     (8 parity classes, Cn = 64: stays on another kernel), input gradient of ConvTranspose3d 384->64 (stride-2 gather,
-    Cn = 384 = 1.5 column tiles).  Every row tile is ragged (rows < 192 or not a multiple), padding taps on every face."""
+    Cn = 384 = 1.5 column tiles); 65..128 columns take the 192 x 128 tile of the same kernel (128->128, 256->128, the stride-2
+    32->128 and a 3/4-full 64->96).  Every row tile is ragged (rows < 192 or not a multiple), padding taps on every face."""
     _check_conv_module(kind, cin, cout, shape)
 
 
