@@ -66,9 +66,9 @@ class _NormAct:
         a_ptr = plan.store.p_ptr(self.alpha)
         plan.emit("ctseg_instnorm_prelu_bwd_reduce", plan.dt, g.ptr(), g.ld, y.ptr(), y.ld, self.mr.data_ptr(), a_ptr,
                   part.data_ptr(), P, ld, N, S, C, keep=(g, part))
-        da_part = torch.zeros(N * C, dtype=torch.float64, device=plan.device)
+        da_part = torch.zeros(N * C + 1, dtype=torch.float64, device=plan.device)     # + completion counter
         plan.emit("ctseg_instnorm_prelu_bwd_finalize", part.data_ptr(), N, P, ld, C, float(S), da_part.data_ptr(), sums.data_ptr(),
-                  None, keep=(sums, da_part))
+                  plan.store.g_ptr(self.alpha), keep=(sums, da_part))
         args = (plan.dt, g.ptr(), g.ld, y.ptr(), y.ld, self.mr.data_ptr(), a_ptr, sums.data_ptr(), dy_out.ptr(), dy_out.ld,
                 g_copy.ptr() if g_copy is not None else None, g_copy.ld if g_copy is not None else 0, N, S, C)
         if colsum_out is None:
@@ -78,8 +78,6 @@ class _NormAct:
             cs_part = torch.zeros((p_cap, rup(C, nat.epc(plan.dt))), dtype=torch.float32, device=plan.device)
             plan.emit("ctseg_instnorm_prelu_bwd_apply_colsum", *args, cs_part.data_ptr(), p_cap, colsum_out,
                       keep=(dy_out, g_copy, cs_part))
-        # PReLU slope gradient: nothing on the critical path needs it -> runs with the weight-gradient work on the side stream
-        plan.emit("ctseg_instnorm_prelu_dalpha", da_part.data_ptr(), N * C, plan.store.g_ptr(self.alpha))
         return dy_out
 
 

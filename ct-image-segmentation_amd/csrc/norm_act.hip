@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_reduce_kernel(const ch
 
 __global__ __launch_bounds__(256) void instnorm_prelu_bwd_finalize_kernel(const float* __restrict__ partials, int P, int ld, int C,
                                                                            double S, float* __restrict__ sums,
-                                                                           double* __restrict__ da_part) {
+                                                                           double* __restrict__ da_part, float* __restrict__ dalpha) {
   // one block per (n, c): 256 strided sub-sums over the P partial rows, combined by a fixed tree (deterministic)
   __shared__ double s_acc[3][256];
   const int i = blockIdx.x, n = i / C, c = i - n * C, t = threadIdx.x;
@@ -179,6 +179,28 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_finalize_kernel(const 
     sums[(int64_t)i * 2 + 1] = (float)(s_acc[1][0] / S);
     da_part[i] = s_acc[2][0];
   }
+  if (dalpha == nullptr) return;
+  // PReLU slope gradient = fixed-order sum of every block's third partial: done by whichever block finishes last (a counter
+  // in the slot behind the gridDim.x partials, reset for the next call) -- no extra launch.  A separate one-block kernel on
+  // the side stream measured 360 us when it was dispatched beside the stride-2 halo pass (it waited for that kernel to end).
+  __shared__ int s_last;
+  const int NC = gridDim.x;
+  unsigned int* counter = reinterpret_cast<unsigned int*>(da_part + NC);
+  __threadfence();
+  __syncthreads();
+  if (t == 0) s_last = (atomicAdd(counter, 1u) == (unsigned)(NC - 1));
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  double a = 0.0;
+  for (int k = t; k < NC; k += 256) a += __builtin_nontemporal_load(&da_part[k]);
+  s_acc[0][t] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) s_acc[0][t] += s_acc[0][t + w];
+    __syncthreads();
+  }
+  if (t == 0) { dalpha[0] = (float)s_acc[0][0]; *counter = 0u; }
 }
 // PReLU slope gradient = sum over every (n, c) of the third partial, fixed order
 __global__ __launch_bounds__(256) void instnorm_prelu_dalpha_kernel(const double* __restrict__ da_part, int NC, float* __restrict__ dalpha) {
@@ -451,8 +473,7 @@ extern "C" int ctseg_instnorm_prelu_bwd_finalize(const float* partials, int32_t 
                                                  double* scratch, float* sums, float* dalpha, void* stream) {
   CTSEG_REQUIRE(partials && scratch && sums && N > 0 && P > 0 && C > 0, "instnorm_prelu_bwd_finalize: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(instnorm_prelu_bwd_finalize_kernel, dim3(N * C), dim3(256), 0, st, partials, P, ld, C, S, sums, scratch);
-  if (dalpha != nullptr) hipLaunchKernelGGL(instnorm_prelu_dalpha_kernel, dim3(1), dim3(256), 0, st, scratch, N * C, dalpha);
+  hipLaunchKernelGGL(instnorm_prelu_bwd_finalize_kernel, dim3(N * C), dim3(256), 0, st, partials, P, ld, C, S, sums, scratch, dalpha);
   CTSEG_LAUNCH_CHECK("instnorm_prelu_bwd_finalize");
   return 0;
 }

@@ -138,9 +138,10 @@ int ctseg_instnorm_prelu_fwd(int32_t dtype, const void* y, int32_t y_ld, const f
 int ctseg_instnorm_prelu_bwd_reduce(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
                                     const float* mean_rstd, const float* alpha, float* partials, int32_t P, int32_t ld,
                                     int32_t N, int64_t S, int32_t C, void* stream);
-/* partials -> sums [N][C][2] (already divided by S) and dalpha (scalar, overwritten); scratch: N*C doubles.
- * dalpha == NULL: only the per-(n,c) slope terms are left in scratch and ctseg_instnorm_prelu_dalpha sums them later (the
- * slope gradient feeds nothing but the optimizer, so the host issues it off the critical path). */
+/* partials -> sums [N][C][2] (already divided by S) and dalpha (scalar, overwritten); scratch: N*C + 1 doubles, the last
+ * one a zero-initialised completion counter (the block that finishes last sums the N*C slope terms in fixed order and
+ * resets it: no extra launch).  dalpha == NULL: only the per-(n,c) slope terms are left in scratch (N*C doubles suffice)
+ * and ctseg_instnorm_prelu_dalpha can sum them later. */
 int ctseg_instnorm_prelu_bwd_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t C, double S,
                                       double* scratch, float* sums, float* dalpha, void* stream);
 int ctseg_instnorm_prelu_dalpha(const double* scratch, int32_t NC, float* dalpha, void* stream);
