@@ -396,6 +396,11 @@ class GemmLayer:
         kpad_w, cn_pad = rup(self.T * cg + 1, 128), rup(cn, bnw)
         nwg = (kpad_w // 128) * (cn_pad // bnw) * N
         splits = max(1, min(math.ceil(2048 / nwg), math.ceil(rows / 512), 1024))
+        # slabs (N * splits) in multiples of 8: the kernel then keeps all K / column blocks of a slab on one XCD (one L2 fetch
+        # of the rows they share instead of one per XCD)
+        m = 8 // math.gcd(N, 8)
+        if splits >= m:
+            splits = splits // m * m
         d = nat.WgradDesc()
         d.in_, d.dy, d.dtype = gathered.ptr(), dyy.ptr(), plan.dt
         d.N, d.Xi, d.Yi, d.Zi = gathered.dims

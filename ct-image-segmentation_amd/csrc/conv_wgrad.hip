@@ -22,6 +22,7 @@ struct WgradKArgs {
   int rows, splits, rows_per_split;
   int kpad_w, cn_pad, d_valid;
   int sx, sy, sz;  // mixed-radix decomposition of a 32-row step
+  int kblocks, cblocks;   // > 0: 1-D grid, workgroup -> (K block, column block, slab) decoded so that one XCD owns a slab
   int taps[CTSEG_MAX_TAPS];
 };
 
@@ -61,8 +62,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
   __syncthreads();
   const int wk = wave / WC, wc = wave % WC;
   const int r16 = lane & 15, q4 = lane >> 4;
-  const int kblock = blockIdx.x, col0 = blockIdx.y * BNW;
-  const int n = blockIdx.z / P.splits, sp = blockIdx.z % P.splits;
+  // Workgroups go to the 8 XCDs round-robin by linear id.  With the plain 3-D grid the K / column blocks of one slab (the
+  // same rows of `in` and `dy`) land on different XCDs and each XCD's L2 fetches its own copy.  1-D grid: ids L, L+8, L+16, ...
+  // inside a group of 8 * kblocks * cblocks are the blocks of ONE slab -> same XCD, dispatched together, one fetch.
+  int kblock, cblock, zslab;
+  if (P.kblocks > 0) {
+    const int kc = P.kblocks * P.cblocks, G = 8 * kc;
+    const int L = blockIdx.x, g = L / G, r = L - g * G;
+    const int q = r >> 3;
+    zslab = g * 8 + (r & 7);
+    kblock = q % P.kblocks;
+    cblock = q / P.kblocks;
+  } else {
+    kblock = blockIdx.x; cblock = blockIdx.y; zslab = blockIdx.z;
+  }
+  const int col0 = cblock * BNW;
+  const int n = zslab / P.splits, sp = zslab % P.splits;
   const int mstart = sp * P.rows_per_split;
   int mend = mstart + P.rows_per_split;
   if (mend > P.rows) mend = P.rows;
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
     __syncthreads();
   }
 
-  float* slab = P.ws + ((int64_t)blockIdx.z * P.kpad_w + kblock * 128) * P.cn_pad + col0;
+  float* slab = P.ws + ((int64_t)zslab * P.kpad_w + kblock * 128) * P.cn_pad + col0;
 #pragma unroll
   for (int i = 0; i < KT; ++i)
 #pragma unroll
@@ -333,9 +348,16 @@ bool wgrad_halo_eligible(const ctseg_wgrad_desc* d);
 int wgrad_halo_slabs(const ctseg_wgrad_desc* d);
 void launch_wgrad_halo(const ctseg_wgrad_desc* d, hipStream_t st);
 
-template <typename T, bool SMALLC> static void launch_wgrad(const WgradKArgs& a, hipStream_t st) {
+template <typename T, bool SMALLC> static void launch_wgrad(WgradKArgs& a, hipStream_t st) {
   const int bnw = ctseg_wgrad_tile_cols(a.Cn);
-  dim3 grid((unsigned)(a.kpad_w / 128), (unsigned)(a.cn_pad / bnw), (unsigned)(a.N * a.splits));
+  const int kb = a.kpad_w / 128, cb = a.cn_pad / bnw, zs = a.N * a.splits;
+  static const bool remap = !(getenv("CTSEG_WGRAD_XCD") && atoi(getenv("CTSEG_WGRAD_XCD")) == 0);
+  dim3 grid((unsigned)kb, (unsigned)cb, (unsigned)zs);
+  a.kblocks = a.cblocks = 0;
+  if (remap && zs % 8 == 0 && kb * cb > 1) {
+    a.kblocks = kb; a.cblocks = cb;
+    grid = dim3((unsigned)(kb * cb * zs), 1u, 1u);
+  }
   if (bnw == 16) hipLaunchKernelGGL((conv_wgrad_kernel<T, 16, 4, 1, SMALLC>), grid, dim3(256), 0, st, a);
   else if (bnw == 32) hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 2, 2, SMALLC>), grid, dim3(256), 0, st, a);
   else if (bnw == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 2, 2, SMALLC>), grid, dim3(256), 0, st, a);
