@@ -21,7 +21,16 @@ struct ConvKArgs {
   // split output (ctseg_conv_desc::out2): columns >= out2_col0 go to out2; stem and stride-2 halo kernels only
   char* out2;
   int out2_col0, o2_ld;
+  int xcd_order;   // generic / ring kernels: grid.x = 8 * ceil(tiles*N / 8), workgroup L takes tile (L&7)*chunk + (L>>3)
 };
+
+// Workgroups reach the 8 XCDs round-robin by linear id.  Tile = (L & 7) * chunk + (L >> 3) gives every XCD one contiguous
+// range of row tiles, so the halo rows neighbouring tiles share are fetched by ONE L2 instead of by all eight.  -1: no tile.
+__device__ __forceinline__ int xcd_tile(int L, int total) {
+  const int chunk = (total + 7) >> 3, i = L >> 3;
+  const int t = (L & 7) * chunk + i;
+  return (i < chunk && t < total) ? t : -1;
+}
 
 template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag);
 template <> __device__ __forceinline__ void mma16<BF16>(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag) {

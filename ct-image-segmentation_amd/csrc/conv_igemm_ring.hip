@@ -187,7 +187,12 @@ __global__ __launch_bounds__(512) void conv_igemm_ring_kernel(const ConvKArgs P)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x % P.tiles, n = blockIdx.x / P.tiles;
+  int bx = blockIdx.x;
+  if (P.xcd_order) {
+    bx = xcd_tile(bx, P.tiles * P.N);
+    if (bx < 0) return;
+  }
+  const int tile = bx % P.tiles, n = bx / P.tiles;
   const int col0 = blockIdx.y * BN;
   const ctseg_conv_class& K = P.cls[blockIdx.z];
   const int ntaps = K.ntaps;
@@ -237,11 +242,12 @@ bool conv_ring_eligible(const ConvKArgs& a, int dtype, int nclass) {
 }
 
 void launch_conv_ring(const ConvKArgs& a, int nclass, hipStream_t st) {
+  const int gx = a.xcd_order ? 8 * ((a.tiles * a.N + 7) / 8) : a.tiles * a.N;
   if (a.Cn > 128) {
-    dim3 grid((unsigned)(a.tiles * a.N), (unsigned)((a.Cn + 255) / 256), (unsigned)nclass);
+    dim3 grid((unsigned)gx, (unsigned)((a.Cn + 255) / 256), (unsigned)nclass);
     hipLaunchKernelGGL(conv_igemm_ring_kernel<256>, grid, dim3(512), 0, st, a);
   } else {
-    dim3 grid((unsigned)(a.tiles * a.N), 1u, (unsigned)nclass);
+    dim3 grid((unsigned)gx, 1u, (unsigned)nclass);
     hipLaunchKernelGGL(conv_igemm_ring_kernel<128>, grid, dim3(512), 0, st, a);
   }
 }
