@@ -125,15 +125,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
     ones = s16x8{o, o, o, o, o, o, o, o};
   }
 
-  int t = blockIdx.x, cur = 0;
-  if (t < total_tiles) {
+  // tile sequence: each XCD (blockIdx % 8 shares one) owns a contiguous range of tiles and its workgroups walk it round-robin,
+  // so the tiles in flight on one XCD are neighbours and share their halos through that XCD's L2
+  int t = blockIdx.x, tstride = gridDim.x, tlast = total_tiles, cur = 0;
+  if ((gridDim.x & 7) == 0) {
+    const int chunk = (total_tiles + 7) / 8, xcd = blockIdx.x & 7;
+    t = xcd * chunk + (blockIdx.x >> 3);
+    tstride = gridDim.x >> 3;
+    tlast = (xcd + 1) * chunk < total_tiles ? (xcd + 1) * chunk : total_tiles;
+  }
+  if (t < tlast) {
     gload(t);
     sstore(0);
   }
   __syncthreads();
-  for (; t < total_tiles; t += gridDim.x) {
-    const int tn = t + gridDim.x;
-    if (tn < total_tiles) gload(tn);
+  for (; t < tlast; t += tstride) {
+    const int tn = t + tstride;
+    if (tn < tlast) gload(tn);
     const char* xs = smem + cur * BUF;
     const char* ds = xs + XBYTES;
 #pragma unroll 2
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
       }
     }
     __syncthreads();
-    if (tn < total_tiles) sstore(cur ^ 1);
+    if (tn < tlast) sstore(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
