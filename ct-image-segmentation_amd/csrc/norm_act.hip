@@ -107,8 +107,12 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_reduce_kernel(const ch
                                                                          float* __restrict__ partials, int P, int ld, int64_t S,
                                                                          int C, int Cv) {
   constexpr int SZ = TT<T>::SZ;   // EPC: elements per chunk (a row is Cv chunks of EPC elements)
-  __shared__ float s_red[256 * 3 * EPC];
+  // dynamic LDS: [2*C] mean/rstd, then the cross-thread reduction scratch -- 4 waves x Cv x 3 x EPC floats when Cv is a power
+  // of two <= 64 (wave butterflies first), else one slot per thread.  The footprint matters: this pass shares the CUs with
+  // the weight-gradient kernels of the side stream, and at 24 KB per block few of its blocks found room beside them.
   extern __shared__ float s_mr[];
+  float* const s_red = s_mr + 2 * C;
+  const bool pow2 = (Cv & (Cv - 1)) == 0 && Cv <= 64;
   const int p = blockIdx.x, n = blockIdx.y;
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_mr[i] = mean_rstd[(int64_t)n * C * 2 + i];
   __syncthreads();
@@ -138,6 +142,35 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_reduce_kernel(const ch
         }
       }
     }
+  }
+  if (pow2) {
+    // lanes l, l + Cv, l + 2 Cv ... of a wave hold the same channel chunk (64 % Cv == 0): xor butterfly, then 4 waves via LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+      for (int o = 32; o >= Cv; o >>= 1) {
+        a1[e] += __shfl_xor(a1[e], o, 64);
+        a2[e] += __shfl_xor(a2[e], o, 64);
+        a3[e] += __shfl_xor(a3[e], o, 64);
+      }
+    if (lane < Cv) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        s_red[((wave * Cv + lane) * 3 + 0) * EPC + e] = a1[e];
+        s_red[((wave * Cv + lane) * 3 + 1) * EPC + e] = a2[e];
+        s_red[((wave * Cv + lane) * 3 + 2) * EPC + e] = a3[e];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
+      const int which = i / C, c = i - which * C;
+      const int ccv = c / EPC, e = c - ccv * EPC;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += s_red[((w * Cv + ccv) * 3 + which) * EPC + e];
+      partials[(((int64_t)n * P + p) * 3 + which) * ld + c] = s;
+    }
+    return;
   }
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
@@ -456,7 +489,10 @@ extern "C" int ctseg_instnorm_prelu_bwd_reduce(int32_t dtype, const void* g, int
   CTSEG_REQUIRE(g && y && mean_rstd && alpha && partials && P > 0 && N > 0 && C <= ld, "instnorm_prelu_bwd_reduce: bad arguments");
   CHECK_CL_HALF(dtype, C, g_ld, y_ld);
   CTSEG_REQUIRE(Cv <= 256, "instnorm_prelu_bwd_reduce: too many channels");
-  const size_t sh = 2 * C * sizeof(float);
+  const bool pow2 = (Cv & (Cv - 1)) == 0 && Cv <= 64;
+  // reduction scratch: 4 waves x Cv chunks (butterfly path) or one slot per thread; padding it to the old 24 KB measured
+  // 12.45 -> 12.49 ms/step (fewer of these blocks fit beside the side stream's weight-gradient workgroups)
+  const size_t sh = (2 * C + (pow2 ? 4 * Cv * 3 * EPC_ : 256 * 3 * EPC_)) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
 #define CTSEG_RED(T, EP)                                                                                                     \
   hipLaunchKernelGGL((instnorm_prelu_bwd_reduce_kernel<T, EP>), dim3(P, N), dim3(256), sh, st, (const char*)g, g_ld,         \
