@@ -191,8 +191,9 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_reduce_kernel(const ch
 __global__ __launch_bounds__(256) void instnorm_prelu_bwd_finalize_kernel(const float* __restrict__ partials, int P, int ld, int C,
                                                                            double S, float* __restrict__ sums,
                                                                            double* __restrict__ da_part, float* __restrict__ dalpha) {
-  // one block per (n, c): 256 strided sub-sums over the P partial rows, combined by a fixed tree (deterministic)
-  __shared__ double s_acc[3][256];
+  // one block per (n, c): 256 strided sub-sums over the P partial rows, combined by a fixed tree (deterministic): wave
+  // butterflies, then the four wave sums in order -- a few bytes of LDS, so the block fits on a CU whatever else runs there
+  __shared__ double s_acc[3][4];
   const int i = blockIdx.x, n = i / C, c = i - n * C, t = threadIdx.x;
   double s1 = 0.0, s2 = 0.0, s3 = 0.0;
   for (int p = t; p < P; p += 256) {
@@ -201,16 +202,16 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_finalize_kernel(const 
     s2 += (double)q[ld];
     s3 += (double)q[2 * ld];
   }
-  s_acc[0][t] = s1; s_acc[1][t] = s2; s_acc[2][t] = s3;
+  s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+  if ((t & 63) == 0) { s_acc[0][t >> 6] = s1; s_acc[1][t >> 6] = s2; s_acc[2][t >> 6] = s3; }
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (t < w) { s_acc[0][t] += s_acc[0][t + w]; s_acc[1][t] += s_acc[1][t + w]; s_acc[2][t] += s_acc[2][t + w]; }
-    __syncthreads();
-  }
   if (t == 0) {
-    sums[(int64_t)i * 2] = (float)(s_acc[0][0] / S);
-    sums[(int64_t)i * 2 + 1] = (float)(s_acc[1][0] / S);
-    da_part[i] = s_acc[2][0];
+    const double r1 = ((s_acc[0][0] + s_acc[0][1]) + s_acc[0][2]) + s_acc[0][3];
+    const double r2 = ((s_acc[1][0] + s_acc[1][1]) + s_acc[1][2]) + s_acc[1][3];
+    const double r3 = ((s_acc[2][0] + s_acc[2][1]) + s_acc[2][2]) + s_acc[2][3];
+    sums[(int64_t)i * 2] = (float)(r1 / S);
+    sums[(int64_t)i * 2 + 1] = (float)(r2 / S);
+    da_part[i] = r3;
   }
   if (dalpha == nullptr) return;
   // PReLU slope gradient = fixed-order sum of every block's third partial: done by whichever block finishes last (a counter
@@ -227,13 +228,11 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_finalize_kernel(const 
   __threadfence();
   double a = 0.0;
   for (int k = t; k < NC; k += 256) a += __builtin_nontemporal_load(&da_part[k]);
-  s_acc[0][t] = a;
+  a = wave_sum(a);
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (t < w) s_acc[0][t] += s_acc[0][t + w];
-    __syncthreads();
-  }
-  if (t == 0) { dalpha[0] = (float)s_acc[0][0]; *counter = 0u; }
+  if ((t & 63) == 0) s_acc[0][t >> 6] = a;
+  __syncthreads();
+  if (t == 0) { dalpha[0] = (float)(((s_acc[0][0] + s_acc[0][1]) + s_acc[0][2]) + s_acc[0][3]); *counter = 0u; }
 }
 // PReLU slope gradient = sum over every (n, c) of the third partial, fixed order
 __global__ __launch_bounds__(256) void instnorm_prelu_dalpha_kernel(const double* __restrict__ da_part, int NC, float* __restrict__ dalpha) {
