@@ -130,6 +130,14 @@ def test_ring_pipelined_tile_vs_torch_cpu(kind, cin, cout, shape):
     _check_conv_module(kind, cin, cout, shape)
 
 
+@pytest.mark.parametrize("kind,cin,cout,shape", [("conv", 64, 64, (1, 16, 16, 16)), ("conv_s2", 32, 128, (2, 32, 32, 16)),
+                                                 ("convT", 64, 16, (2, 16, 16, 16)), ("conv", 128, 256, (1, 16, 16, 16))])
+def test_weight_gradient_with_xcd_grouped_slabs_vs_torch_cpu(kind, cin, cout, shape):
+    """shapes whose weight gradient runs N * splits = 8 or 16 slabs: the generic kernel then takes its 1-D grid in which the
+    K / column blocks of one slab are workgroups L, L+8, L+16 ... (one XCD per slab); 14 / 7 / 4 / 27 K blocks, 1-2 column blocks"""
+    _check_conv_module(kind, cin, cout, shape)
+
+
 def _check_conv_module(kind, cin, cout, shape):
     """passes that take conv_halo_sw (bf16): 64->64 k3 s1 forward + input gradient (one class), ConvTranspose3d 128->32
     forward and the input gradient of a stride-2 conv 32->128 (8 parity classes); both tile-axis mappings, ragged tiles."""
