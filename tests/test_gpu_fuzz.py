@@ -16,6 +16,9 @@ CASES = [
     ((8, 16, 32, 64), 1, (48, 16, 40), "fp32"),       # fp32 MFMA path, 4 levels, z = 40 -> tiles of 8 exactly, y = 16
     ((32, 64), 2, (20, 36, 28), "fp32"),              # two levels, sizes divisible by 2 only
     ((16, 32, 64, 128), 1, (32, 64, 48), "bf16"),     # 4 levels; 12-deep style z at level 2 (48/4 = 12): permuted tile axes
+    ((32, 64, 128, 256), 2, (32, 32, 16), "bf16"),    # the benchmark's channels: ring-pipelined 192x256 / 192x128 tiles on ragged
+                                                      # 32- and 256-row grids, 12-wide rows around the logits conv
+    ((32, 64, 128), 4, (16, 32, 16), "bf16"),         # N = 4: weight-gradient slab counts rounded to multiples of 8 (XCD-grouped grid)
 ]
 
 
