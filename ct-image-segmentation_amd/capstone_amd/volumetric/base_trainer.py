@@ -165,7 +165,7 @@ class BaseUNet3D(_Base):
             plan.backward()
             scale = 1.0
         eng.store.adam_step(self.hparams.lr, betas, eps, grad_scale=scale)
-        plan.packer.dirty = True
+        plan.repack_after_update()
         total = torch.stack([vals[n] for n in names]).sum()
         dice_mean, dice_per_class = le.dice_metric()
         for n in names:
