@@ -102,13 +102,21 @@ class SegLossEngine:
             nat.call("ctseg_reduce_partials_f64", self.part.data_ptr(), self.B, self.P, self.R, self.red_w.data_ptr())
             self.cnt.copy_(keep)
 
-    def fused_ce(self, logits_ptr, ld, dl_ptr, g_ld, gdt, weighted=False):
-        """CrossEntropy (or WeightedCrossEntropy) alone: stats + gradient in ONE pass (upstream gradient 1)."""
+    def prepare_fused_ce(self, weighted=False):
+        """the part of fused_ce that needs only the label histogram (counters zeroed, 1/denominator table): the training step
+        issues it on the side stream right behind the mask squash, off the forward -> loss critical path"""
         self.cnt.zero_()
         w = self.cw.double() if weighted else torch.ones(self.C, dtype=torch.float64, device=self.device)
         denom = (self.hist.double() * w[None, :]).sum()
         self.coef.zero_()
         self.coef[:, 0] = (1.0 / denom).float()
+        self._ce_ready = weighted
+
+    def fused_ce(self, logits_ptr, ld, dl_ptr, g_ld, gdt, weighted=False):
+        """CrossEntropy (or WeightedCrossEntropy) alone: stats + gradient in ONE pass (upstream gradient 1)."""
+        if getattr(self, "_ce_ready", None) is not weighted:
+            self.prepare_fused_ce(weighted)
+        self._ce_ready = None
         self._pass(logits_ptr, ld, self.cw if weighted else None, 2, 2, self.coef, dl_ptr, g_ld, gdt)
         nat.call("ctseg_reduce_partials_f64", self.part.data_ptr(), self.B, self.P, self.R,
                  (self.red_w if weighted else self.red).data_ptr())

@@ -131,26 +131,31 @@ class BaseUNet3D(_Base):
         eng = self.unet.engine()
         plan = eng.plan_for(images)
         side = plan.side_stream()
+        le = getattr(plan, "_ctseg_loss", None)
+        if le is None:
+            le = plan._ctseg_loss = segloss.SegLossEngine(images.device, images.shape[0], plan.logits.S, self._n_classes)
+        names = list(self.loss_func.names)
+        ce_only = len(names) == 1 and names[0] in ("CrossEntropy", "WeightedCrossEntropy")
         if side is not None:
-            # the label map is not needed before the loss: squash the masks on the side stream while the forward pass starts
+            # the label map is not needed before the loss: squash the masks (and build the loss tables that need only the label
+            # histogram) on the side stream while the forward pass starts
             main = torch.cuda.current_stream(images.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 lab_u8, _, hist = segloss.squash_masks(masks, self._n_classes, want_i64=False)
+                le.set_labels(lab_u8, hist)
+                if ce_only:
+                    le.prepare_fused_ce(weighted=names[0] != "CrossEntropy")
             for t in (lab_u8, hist):
                 t.record_stream(main)
             logits = plan.forward(images)
             main.wait_stream(side)
         else:
             lab_u8, _, hist = segloss.squash_masks(masks, self._n_classes, want_i64=False)
+            le.set_labels(lab_u8, hist)
             logits = plan.forward(images)
-        le = getattr(plan, "_ctseg_loss", None)
-        if le is None:
-            le = plan._ctseg_loss = segloss.SegLossEngine(images.device, images.shape[0], logits.S, self._n_classes)
-        le.set_labels(lab_u8, hist)
-        names = list(self.loss_func.names)
         dl = plan.dlogits
-        if len(names) == 1 and names[0] in ("CrossEntropy", "WeightedCrossEntropy"):
+        if ce_only:
             le.fused_ce(logits.ptr(), logits.ld, dl.ptr(), dl.ld, plan.dt, weighted=names[0] != "CrossEntropy")
             vals = le.loss_values(names)
         else:
