@@ -388,8 +388,10 @@ class Plan:
             self._side_ev = {}
             self._join_ev = torch.cuda.Event()
 
-    def backward(self, hooks=None):
-        """runs the recorded backward; ``hooks`` = {program index: callable} fire between ops (DDP overlap)"""
+    def backward(self, hooks=None, before_join=None):
+        """runs the recorded backward; ``hooks`` = {program index: callable} fire between ops (DDP overlap).  ``before_join``:
+        called once every op is queued but before the main stream waits for the side stream's tail (the last weight gradients,
+        ~0.15 ms): main-stream work that does not need the gradients (scalar bookkeeping) goes there for free."""
         if self.inference:
             raise RuntimeError("this plan was recorded for inference (torch.no_grad()); run the forward with gradients enabled first")
         hooks = hooks or {}
@@ -401,6 +403,8 @@ class Plan:
                 hooks[idx]()
                 lo = idx
             self.run(self.bwd, st, lo)
+            if before_join is not None:
+                before_join()
             return
         self._side_setup()
         main, side = torch.cuda.current_stream(self.device), self._side
@@ -430,6 +434,8 @@ class Plan:
                 busy = True
             else:
                 self.run(self.bwd, st, a, b)
+        if before_join is not None:
+            before_join()
         join()
         if n in hooks:
             hooks[n]()

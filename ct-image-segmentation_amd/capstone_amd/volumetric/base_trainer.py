@@ -155,24 +155,32 @@ class BaseUNet3D(_Base):
             le.set_labels(lab_u8, hist)
             logits = plan.forward(images)
         dl = plan.dlogits
+        vals = None
         if ce_only:
             le.fused_ce(logits.ptr(), logits.ld, dl.ptr(), dl.ld, plan.dt, weighted=names[0] != "CrossEntropy")
-            vals = le.loss_values(names)
         else:
             le.stats(logits.ptr(), logits.ld, weighted_too="WeightedCrossEntropy" in names)
             vals = le.loss_values(names, self.loss_func.exclude_missing, mask_indicator.float())
             le.build_coef({n: 1.0 for n in names})
             le.grad(logits.ptr(), logits.ld, dl.ptr(), dl.ld, plan.dt)
+        book = {}
+
+        def bookkeeping():     # ~20 scalar-sized kernels: queued behind the backward pass, beside the side stream's tail
+            v = vals if vals is not None else le.loss_values(names)
+            book["vals"] = v
+            book["total"] = torch.stack([v[n] for n in names]).sum()
+            book["dice"] = le.dice_metric()
+
         if self.reducer is not None:
-            plan.backward(self.reducer.hooks(plan))
+            plan.backward(self.reducer.hooks(plan), before_join=bookkeeping)
             scale = self.reducer.finish()
         else:
-            plan.backward()
+            plan.backward(before_join=bookkeeping)
             scale = 1.0
         eng.store.adam_step(self.hparams.lr, betas, eps, grad_scale=scale)
         plan.repack_after_update()
-        total = torch.stack([vals[n] for n in names]).sum()
-        dice_mean, dice_per_class = le.dice_metric()
+        vals, total = book["vals"], book["total"]
+        dice_mean, dice_per_class = book["dice"]
         for n in names:
             self.log(f"{n} Loss (train)", vals[n])
         self.log("Mean Dice Score (train)", dice_mean)
