@@ -121,6 +121,14 @@ class SegLossEngine:
         nat.call("ctseg_reduce_partials_f64", self.part.data_ptr(), self.B, self.P, self.R,
                  (self.red_w if weighted else self.red).data_ptr())
 
+    def ce_summary(self, weighted=False):
+        """(loss, mean Dice, Dice per class) of the last fused_ce pass as views of one small tensor: one launch instead of the
+        ~20 scalar-sized torch kernels of loss_values() + dice_metric()"""
+        out = torch.empty(1 + self.C, dtype=torch.float32, device=self.device)
+        nat.call("ctseg_loss_dice_summary", (self.red_w if weighted else self.red).data_ptr(), self.B, self.R, self.cnt.data_ptr(),
+                 self.C, out.data_ptr())
+        return out[0], out[1], out[2:]
+
     def predictions(self, logits_ptr, ld):
         pred = torch.empty((self.B, self.S), dtype=torch.uint8, device=self.device)
         if self.labels is None:

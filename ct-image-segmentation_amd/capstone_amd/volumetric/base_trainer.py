@@ -165,10 +165,13 @@ class BaseUNet3D(_Base):
             le.grad(logits.ptr(), logits.ld, dl.ptr(), dl.ld, plan.dt)
         book = {}
 
-        def bookkeeping():     # ~20 scalar-sized kernels: queued behind the backward pass, beside the side stream's tail
-            v = vals if vals is not None else le.loss_values(names)
-            book["vals"] = v
-            book["total"] = torch.stack([v[n] for n in names]).sum()
+        def bookkeeping():     # scalar-sized work: queued behind the backward pass, beside the side stream's tail
+            if ce_only:        # one launch for loss + Dice
+                loss, dm, dpc = le.ce_summary(weighted=names[0] != "CrossEntropy")
+                book["vals"], book["total"], book["dice"] = {names[0]: loss}, loss, (dm, dpc)
+                return
+            book["vals"] = vals
+            book["total"] = torch.stack([vals[n] for n in names]).sum()
             book["dice"] = le.dice_metric()
 
         if self.reducer is not None:

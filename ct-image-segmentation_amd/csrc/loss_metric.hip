@@ -280,9 +280,48 @@ __global__ __launch_bounds__(256) void reduce_partials_f64_kernel(const double* 
   if (t == 0) out[(int64_t)b * R + r] = s[0];
 }
 
+// The scalar bookkeeping of a cross-entropy training step in ONE launch instead of ~20 scalar-sized torch kernels:
+// out[0] = sum_b red[b][0] / sum_b red[b][1] (mean cross-entropy), out[2 + k] = Dice of foreground class k+1 averaged over the
+// samples whose ground truth holds it ("mean_batch" with NaN for an empty truth, capstone/models/metrics.py:15-31), 0 when
+// no sample does; out[1] = their mean over the C-1 foreground classes.  fp32 arithmetic in the order of the torch expressions.
+__global__ __launch_bounds__(64) void loss_dice_summary_kernel(const double* __restrict__ red, int B, int R,
+                                                                 const long long* __restrict__ cnt, int C, float* __restrict__ out) {
+  __shared__ float s_pc[CMAX];
+  const int t = threadIdx.x;
+  if (t < C - 1) {
+    const int c = t + 1;
+    float sum = 0.f, n_ok = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float inter = (float)cnt[((int64_t)b * 3 + 0) * C + c], pred = (float)cnt[((int64_t)b * 3 + 1) * C + c],
+                  truth = (float)cnt[((int64_t)b * 3 + 2) * C + c];
+      if (truth > 0.f) { sum += 2.0f * inter / (truth + pred); n_ok += 1.f; }
+    }
+    const float pc = n_ok > 0.f ? sum / n_ok : 0.f;
+    s_pc[t] = pc;
+    out[2 + t] = pc;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double a = 0.0, w = 0.0;
+    for (int b = 0; b < B; ++b) { a += red[(int64_t)b * R]; w += red[(int64_t)b * R + 1]; }
+    out[0] = (float)(a / w);
+    float m = 0.f;
+    for (int k = 0; k < C - 1; ++k) m += s_pc[k];
+    out[1] = m / (float)(C - 1);
+  }
+}
+
 }  // namespace ctseg
 
 using namespace ctseg;
+
+extern "C" int ctseg_loss_dice_summary(const double* red, int32_t B, int32_t R, const int64_t* cnt, int32_t C, float* out,
+                                       void* stream) {
+  CTSEG_REQUIRE(red && cnt && out && B > 0 && R >= 2 && C >= 2 && C <= CMAX, "loss_dice_summary: bad arguments");
+  hipLaunchKernelGGL(loss_dice_summary_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, red, B, R, (const long long*)cnt, C, out);
+  CTSEG_LAUNCH_CHECK("loss_dice_summary");
+  return 0;
+}
 
 extern "C" int ctseg_squash_masks(const uint8_t* masks, int32_t B, int32_t K, int64_t S, uint8_t* labels, int64_t* labels_i64,
                                   int64_t* hist, void* stream) {

@@ -183,6 +183,11 @@ int ctseg_seg_loss(const float* logits, int32_t ld, const uint8_t* labels, int32
 int ctseg_dice_counts(const uint8_t* pred, const uint8_t* truth, int32_t B, int64_t S, int32_t C, int64_t* cnt, void* stream);
 /* part [B][P][R] doubles -> out [B][R] doubles, fixed order */
 int ctseg_reduce_partials_f64(const double* part, int32_t B, int32_t P, int32_t R, double* out, void* stream);
+/* One launch for the scalars a cross-entropy training step logs (capstone/volumetric/base_trainer.py:80-82, 98-110 ->
+ * capstone/models/losses.py:45-68 and metrics.py:15-31): out[0] = sum_b red[b][0] / sum_b red[b][1] with red = the reduced
+ * ctseg_seg_loss records (entry 0 = weighted NLL sum, 1 = weight sum); out[2 + k] = Dice of class k+1 averaged over the
+ * samples whose truth holds it (0 if none), from cnt[B][3][C]; out[1] = mean of those C-1 values.  out: 1 + C floats. */
+int ctseg_loss_dice_summary(const double* red, int32_t B, int32_t R, const int64_t* cnt, int32_t C, float* out, void* stream);
 
 /* torch.optim.Adam step (capstone/volumetric/base_trainer.py:113-114) on flat fp32 buffers. */
 int ctseg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

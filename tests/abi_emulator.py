@@ -283,6 +283,19 @@ class Emulator:
         assert sd == F32 and dd == F32
         mem(dst, n)[:] = mem(src, n)
 
+    def loss_dice_summary(self, red, B, R, cnt, C, out):
+        r = mem(red, B * R, np.float64).reshape(B, R)
+        c = mem(cnt, B * 3 * C, np.int64).reshape(B, 3, C).astype(np.float32)
+        o = mem(out, 1 + C)
+        o[0] = np.float32(r[:, 0].sum() / r[:, 1].sum())
+        inter, pred, true = c[:, 0, 1:], c[:, 1, 1:], c[:, 2, 1:]
+        ok = true > 0
+        score = np.where(ok, 2.0 * inter / np.where(ok, true + pred, 1.0), 0.0).astype(np.float32)
+        n_ok = ok.sum(0).astype(np.float32)
+        pc = np.where(n_ok > 0, score.sum(0) / np.maximum(n_ok, 1), 0.0).astype(np.float32)
+        o[2:2 + C - 1] = pc
+        o[1] = pc.mean(dtype=np.float32)
+
     def nc_to_cl(self, src, dst, dtype, N, C, S, ld):
         s = mem(src, N * C * S).reshape(N, C, S)
         d = mem(dst, N * S * ld).reshape(N, S, ld)

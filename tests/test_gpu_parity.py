@@ -611,3 +611,25 @@ def test_narrow_rows_fall_back_where_a_pass_cannot_move_them(monkeypatch):
     m = BaseUNet3D(filters=[16, 32], loss_fx=["CrossEntropy"], precision="bf16").to(DEV)
     loss = float(m.fit_step((images, masks, ind)))
     assert np.isfinite(loss) and m.unet.engine().last_plan.dlogits.ld == 16
+
+
+def test_loss_dice_summary_kernel_matches_the_torch_expressions():
+    """ctseg_loss_dice_summary (one launch) against SegLossEngine.loss_values + dice_metric (the torch expressions it replaces),
+    with classes absent from some / all samples (NaN -> excluded from the batch mean, 0 when no sample holds the class)"""
+    B, S, C = 3, 4096, 10
+    le = segloss.SegLossEngine(torch.device(DEV), B, S, C)
+    g = torch.Generator().manual_seed(31)
+    le.red.copy_(torch.rand(B, le.R, generator=g, dtype=torch.float64) * 100 + 1)
+    cnt = torch.randint(0, 500, (B, 3, C), generator=g, dtype=torch.int64)
+    cnt[:, 2, 3] = 0            # class 3 absent everywhere
+    cnt[1, 2, 5] = 0            # class 5 absent in one sample
+    cnt[:, 0] = torch.minimum(cnt[:, 0], torch.minimum(cnt[:, 1], cnt[:, 2]))
+    le.cnt.copy_(cnt)
+    le.hist = cnt[:, 2].clone().to(DEV)
+    want_loss = le.loss_values(["CrossEntropy"])["CrossEntropy"]
+    want_mean, want_pc = le.dice_metric()
+    loss, dm, dpc = le.ce_summary()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(want_loss)) <= 1e-6 * abs(float(want_loss))
+    assert torch.allclose(dpc.cpu(), want_pc.cpu(), rtol=1e-6, atol=1e-7) and float(dpc[2]) == 0.0
+    assert abs(float(dm) - float(want_mean)) <= 1e-6
