@@ -17,34 +17,59 @@ constexpr int FIN_GROUPS = 64;
 __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __restrict__ part, int P, int ld, int col0, int C,
                                                                 double count, double eps, double* __restrict__ scratch,
                                                                 unsigned int* __restrict__ counter, float* __restrict__ mean_rstd) {
+  // This launch sits between every conv and its norm pass with nothing to overlap it: what counts is the length of its
+  // dependent-load chains, so both levels spread their sums over all 256 threads.
   __shared__ int s_last;
-  const int g = blockIdx.x, n = blockIdx.y, rowlen = 2 * ld;
+  __shared__ double s_sub[256];
+  const int g = blockIdx.x, n = blockIdx.y, rowlen = 2 * ld, t = threadIdx.x;
   const int F = (P + FIN_GROUPS - 1) / FIN_GROUPS;
   const int p0 = g * F, p1 = (p0 + F < P) ? p0 + F : P;
-  for (int j = threadIdx.x; j < rowlen; j += blockDim.x) {
+  // level 1: nj columns x R row lanes; lane r sums rows p0 + r, p0 + r + R, ...; the R sub-sums combine in lane order
+  const int nj = rowlen < 256 ? rowlen : 256, R = 256 / nj;
+  const int r = t / nj, j0 = t - r * nj;
+  for (int jb = 0; jb < rowlen; jb += nj) {
+    const int j = jb + j0;
     double s = 0.0;
-    for (int p = p0; p < p1; ++p) s += (double)part[((int64_t)n * P + p) * rowlen + j];
-    scratch[((int64_t)n * FIN_GROUPS + g) * rowlen + j] = s;
+    if (r < R && j < rowlen)
+      for (int p = p0 + r; p < p1; p += R) s += (double)part[((int64_t)n * P + p) * rowlen + j];
+    if (R > 1) {
+      s_sub[t] = s;
+      __syncthreads();
+      if (r == 0 && j < rowlen) {
+        for (int k = 1; k < R; ++k) s += s_sub[k * nj + j0];
+      }
+      __syncthreads();
+    }
+    if (r == 0 && j < rowlen) scratch[((int64_t)n * FIN_GROUPS + g) * rowlen + j] = s;
   }
   __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) s_last = (atomicAdd(&counter[n], 1u) == (unsigned)(FIN_GROUPS - 1));
+  if (t == 0) s_last = (atomicAdd(&counter[n], 1u) == (unsigned)(FIN_GROUPS - 1));
   __syncthreads();
   if (!s_last) return;
   __threadfence();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double s = 0.0, q = 0.0;
-    for (int gg = 0; gg < FIN_GROUPS; ++gg) {
-      s += __builtin_nontemporal_load(&scratch[((int64_t)n * FIN_GROUPS + gg) * rowlen + col0 + c]);
-      q += __builtin_nontemporal_load(&scratch[((int64_t)n * FIN_GROUPS + gg) * rowlen + ld + col0 + c]);
+  // level 2 (last block of the sample): L lanes per channel, lane l sums groups l, l + L, ...; xor butterfly over the L lanes
+  int L = 1;
+  while (L * 2 <= FIN_GROUPS && L * 2 * C <= 256) L *= 2;
+  const int per = 256 / L;                       // channels per sweep
+  for (int cb = 0; cb < C; cb += per) {
+    const int c = cb + t / L, l = t & (L - 1);
+    double sm = 0.0, q = 0.0;
+    if (c < C)
+      for (int gg = l; gg < FIN_GROUPS; gg += L) {
+        sm += __builtin_nontemporal_load(&scratch[((int64_t)n * FIN_GROUPS + gg) * rowlen + col0 + c]);
+        q += __builtin_nontemporal_load(&scratch[((int64_t)n * FIN_GROUPS + gg) * rowlen + ld + col0 + c]);
+      }
+    for (int o = L >> 1; o > 0; o >>= 1) { sm += __shfl_xor(sm, o, 64); q += __shfl_xor(q, o, 64); }
+    if (c < C && l == 0) {
+      const double mean = sm / count;
+      double var = q / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      mean_rstd[((int64_t)n * C + c) * 2] = (float)mean;
+      mean_rstd[((int64_t)n * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + eps));
     }
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    mean_rstd[((int64_t)n * C + c) * 2] = (float)mean;
-    mean_rstd[((int64_t)n * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + eps));
   }
-  if (threadIdx.x == 0) counter[n] = 0u;
+  if (t == 0) counter[n] = 0u;
 }
 
 template <typename T, int EPC>
