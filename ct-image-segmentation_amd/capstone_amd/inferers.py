@@ -18,6 +18,8 @@ once on the host and folded into the blend.  No CPU fallback: a predictor that i
 import math
 from typing import Sequence, Union
 
+import os
+
 import numpy as np
 import torch
 
@@ -90,6 +92,33 @@ def _engine_of(predictor):
     return net, net.engine()
 
 
+LAST_DEVICE_BATCH = None     # windows per forward of the most recent call (reporting only)
+
+
+def _device_plan(engine, dev, sw_batch_size, n_windows, roi):
+    """(plan, windows per forward).  Windows are independent samples (InstanceNorm is per sample) and are blended in scan order
+    whatever the grouping, so on a 288 GB device the forward batch need not stay at the caller's ``sw_batch_size`` -- a bound
+    chosen for the memory of smaller GPUs that leaves the 12^3-voxel levels of a 4-window batch on 24 workgroups.
+    CTSEG_SW_DEVICE_BATCH = "auto" (default: up to 48 windows per forward, halved while the plan does not fit), an integer
+    cap, or "0" to run exactly ``sw_batch_size`` windows per forward."""
+    want = os.environ.get("CTSEG_SW_DEVICE_BATCH", "auto")
+    nb = sw_batch_size
+    if dev.type == "cuda" and want != "0":
+        cap = 48 if want == "auto" else max(1, int(want))
+        nb = max(sw_batch_size, min(n_windows, cap))
+    global LAST_DEVICE_BATCH
+    while True:
+        try:
+            plan = engine.plan_for_shape(dev, nb, roi, inference=True)
+            LAST_DEVICE_BATCH = nb
+            return plan, nb
+        except torch.cuda.OutOfMemoryError:
+            if nb <= sw_batch_size:
+                raise
+            torch.cuda.empty_cache()
+            nb = max(sw_batch_size, nb // 2)
+
+
 @torch.no_grad()
 def sliding_window_inference(inputs: torch.Tensor, roi_size: Union[Sequence[int], int], sw_batch_size: int, predictor,
                              overlap: float = 0.25, mode: str = "constant", sigma_scale: float = 0.125,
@@ -121,7 +150,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Union[Sequence[int]
     dev = inputs.device
     imp_d, inv_count = _blend_maps(dev, img, roi, lo, tuple(starts), mode, sigma_scale)
 
-    plan = engine.plan_for_shape(dev, sw_batch_size, roi[:nd], inference=True)
+    plan, sw_batch_size = _device_plan(engine, dev, sw_batch_size, len(starts), roi[:nd])
     vol = inputs.reshape(net.in_channels, *img)
     if vol.dtype != torch.float32 or not vol.is_contiguous():
         vol = vol.float().contiguous()

@@ -118,3 +118,20 @@ def test_sliding_window_2d_and_plan_reuse():
     n_plans = len(net.engine().plans)
     inferers.sliding_window_inference(x.cuda(), (16, 16), 4, net, 0.5, "constant")
     assert len(net.engine().plans) == n_plans           # the inference plan is cached per (batch, ROI)
+
+
+@pytest.mark.gpu
+def test_device_window_batch_changes_nothing_beyond_partial_sum_order(monkeypatch):
+    """the forward batch on the device may be larger than the caller's sw_batch_size (windows are independent samples, blended
+    in scan order either way): same logits up to the order of the fp32 InstanceNorm partial sums, same argmax"""
+    ref, net = _pair(chans=(8, 16, 32), strides=(2, 2), precision="fp32")
+    net = net.cuda()
+    x = torch.randn(1, 1, 40, 36, 24).cuda()
+    monkeypatch.setenv("CTSEG_SW_DEVICE_BATCH", "0")
+    exact = inferers.sliding_window_inference(x, (32, 32, 16), 2, net, 0.25, "gaussian").clone()
+    assert inferers.LAST_DEVICE_BATCH == 2
+    monkeypatch.setenv("CTSEG_SW_DEVICE_BATCH", "auto")
+    auto = inferers.sliding_window_inference(x, (32, 32, 16), 2, net, 0.25, "gaussian")
+    assert inferers.LAST_DEVICE_BATCH == 8          # all 8 windows of this volume in one forward
+    assert (auto - exact).abs().max().item() < 2e-5 * exact.abs().max().item()
+    assert torch.equal(auto.argmax(1), exact.argmax(1))

@@ -40,7 +40,8 @@ def main():
     padded = [max(i, r) for i, r in zip(a.shape, a.roi)]
     nwin = len(inferers._window_starts(padded, a.roi, inferers._scan_interval(padded, a.roi, a.overlap)))
     print(json.dumps({"metric": "sliding-window inference volumes/sec", "value": 1 / dt, "unit": "volumes/s", "ms_per_volume": dt * 1e3,
-                      "windows": nwin, "config": {"volume": a.shape, "roi": a.roi, "sw_batch_size": a.sw_batch, "overlap": a.overlap,
+                      "windows": nwin, "config": {"volume": a.shape, "roi": a.roi, "sw_batch_size": a.sw_batch,
+                                                   "windows_per_forward": inferers.LAST_DEVICE_BATCH, "overlap": a.overlap,
                                                   "mode": a.mode, "channels": a.channels, "precision": a.precision},
                       "finite": bool(torch.isfinite(out).all().item())}))
 
