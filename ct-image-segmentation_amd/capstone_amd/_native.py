@@ -100,7 +100,9 @@ _SIGS = {
     "ctseg_cl_to_nc": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
     "ctseg_resize3d_to_hwd": (C.c_int, [_vp, _i32, _vp] + [_i32] * 8 + [_f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ctseg_window_gather": (C.c_int, [_vp] + [_i32] * 10 + [_f32, _vp, _i32, _i32, _vp]),
+    "ctseg_window_gather_batch": (C.c_int, [_vp] + [_i32] * 4 + [_vp] + [_i32] * 4 + [_f32, _vp, _i32, _i32, _vp]),
     "ctseg_window_blend": (C.c_int, [_vp] + [_i32] * 8 + [_vp, _vp, _vp] + [_i32] * 4 + [_vp]),
+    "ctseg_window_blend_batch": (C.c_int, [_vp] + [_i32] * 5 + [_vp, _i32, _vp, _vp, _vp] + [_i32] * 4 + [_vp, _vp]),
 }
 EXPORTS = tuple(_SIGS)
 _lib = None

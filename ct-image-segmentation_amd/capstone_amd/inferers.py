@@ -15,6 +15,7 @@ dtype, padding on the fly), the recorded forward program of an inference-only pl
 accumulate into the channels-last fp32 output).  The weight normalisation is input independent, so its reciprocal is computed
 once on the host and folded into the blend.  No CPU fallback: a predictor that is not backed by the engine raises.
 """
+import ctypes
 import math
 from typing import Sequence, Union
 
@@ -161,11 +162,26 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Union[Sequence[int]
     win_elems = roi[0] * roi[1] * roi[2]
     esz = xin.t.element_size()
     for g in range(0, len(starts), sw_batch_size):
-        batch = starts[g:g + sw_batch_size]
-        for b, (a, bb, c) in enumerate(batch):               # a short last batch re-runs stale windows; they are not blended
-            nat.call("ctseg_window_gather", vol.data_ptr(), net.in_channels, *img, a - lo[0], bb - lo[1], c - lo[2], *roi,
-                     float(cval), xin.t.data_ptr() + b * win_elems * xin.ld * esz, plan.dt, xin.ld)
+        batch = starts[g:g + sw_batch_size]               # a short last batch re-runs stale windows; they are not blended
+        rel = [[a - lo[0], bb - lo[1], c - lo[2]] for a, bb, c in batch]
+        on_gpu = dev.type == "cuda"
+        if on_gpu:                                            # one gather launch for the batch
+            st_d = torch.tensor(rel, dtype=torch.int32).to(dev, non_blocking=True)
+            nat.call("ctseg_window_gather_batch", vol.data_ptr(), net.in_channels, *img, st_d.data_ptr(), len(batch), *roi, float(cval),
+                     xin.t.data_ptr(), plan.dt, xin.ld)
+        else:
+            for b, (a, bb, c) in enumerate(rel):
+                nat.call("ctseg_window_gather", vol.data_ptr(), net.in_channels, *img, a, bb, c, *roi,
+                         float(cval), xin.t.data_ptr() + b * win_elems * xin.ld * esz, plan.dt, xin.ld)
         plan.forward()
+        if on_gpu and logits.ld == out_ld:
+            # one output-centric launch for the whole batch: same sums in the same (scan) order, the output read / written once
+            b0 = [max(0, min(r[k] for r in rel)) for k in range(3)]
+            b1 = [min(img[k], max(r[k] for r in rel) + roi[k]) for k in range(3)]
+            bbox = (ctypes.c_int32 * 6)(*b0, *[b1[k] - b0[k] for k in range(3)])       # voxels the batch can touch
+            nat.call("ctseg_window_blend_batch", logits.t.data_ptr(), logits.ld, C, *roi, st_d.data_ptr(), len(batch),
+                     imp_d.data_ptr(), inv_count.data_ptr(), out.data_ptr(), *img, out_ld, bbox)
+            continue
         for b, (a, bb, c) in enumerate(batch):
             nat.call("ctseg_window_blend", logits.t.data_ptr() + b * win_elems * logits.ld * 4, logits.ld, C, *roi,
                      a - lo[0], bb - lo[1], c - lo[2], imp_d.data_ptr(), inv_count.data_ptr(), out.data_ptr(), *img, out_ld)

@@ -101,6 +101,27 @@ __global__ void window_gather_kernel(const float* __restrict__ vol, int Cin, int
     dst[i] = cvt<float, TD>(val);
   }
 }
+// every window of a forward batch in one launch (blockIdx.y = window, origins read from the device)
+template <typename TD>
+__global__ void window_gather_batch_kernel(const float* __restrict__ vol, int Cin, int X, int Y, int Z, const int* __restrict__ starts,
+                                           int rx, int ry, int rz, float cval, TD* __restrict__ dst, int ld) {
+  const int w = blockIdx.y;
+  const int x0 = starts[3 * w], y0 = starts[3 * w + 1], z0 = starts[3 * w + 2];
+  const int64_t total = (int64_t)rx * ry * rz * ld;
+  TD* d = dst + (int64_t)w * total;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / ld;
+    const int c = (int)(i - v * ld);
+    const int z = (int)(v % rz), y = (int)((v / rz) % ry), x = (int)(v / ((int64_t)rz * ry));
+    const int gx = x0 + x, gy = y0 + y, gz = z0 + z;
+    float val = 0.f;
+    if (c < Cin) {
+      const bool in = (unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y && (unsigned)gz < (unsigned)Z;
+      val = in ? vol[(((int64_t)c * X + gx) * Y + gy) * Z + gz] : cval;
+    }
+    d[i] = cvt<float, TD>(val);
+  }
+}
 __global__ void window_blend_kernel(const float* __restrict__ logits, int ld, int C, int rx, int ry, int rz, int x0, int y0, int z0,
                                     const float* __restrict__ imp, const float* __restrict__ inv_count, float* __restrict__ out,
                                     int X, int Y, int Z, int out_ld) {
@@ -113,6 +134,49 @@ __global__ void window_blend_kernel(const float* __restrict__ logits, int ld, in
     if ((unsigned)gx >= (unsigned)X || (unsigned)gy >= (unsigned)Y || (unsigned)gz >= (unsigned)Z) continue;   // padded rim
     const int64_t d = ((int64_t)gx * Y + gy) * Z + gz;
     out[d * out_ld + c] += imp[v] * (inv_count ? inv_count[d] : 1.f) * logits[v * ld + c];
+  }
+}
+
+// All windows of one forward batch in ONE launch, output-centric: a thread owns an output voxel and adds, in window order, the
+// weighted logits of every window of the batch that covers it -- the same fp32 sums in the same order as one
+// window_blend_kernel launch per window, but the output row is read and written once per batch instead of once per covering
+// window, rows move as 16-byte vectors, and there is no per-window launch.
+template <int V4>     // float4 groups per row (out_ld = ld = 4 * V4)
+__global__ __launch_bounds__(256) void window_blend_batch_kernel(const float* __restrict__ logits, int C, int rx, int ry, int rz,
+                                                                 const int* __restrict__ starts, int nw,
+                                                                 const float* __restrict__ imp, const float* __restrict__ inv_count,
+                                                                 float* __restrict__ out, int X, int Y, int Z, int bx0, int by0,
+                                                                 int bz0, int bX, int bY, int bZ) {
+  // threads sweep the bounding box (bx0.., extents bX x bY x bZ, inside the volume) of the batch's windows
+  const int64_t total = (int64_t)bX * bY * bZ, wvox = (int64_t)rx * ry * rz;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int gz = bz0 + (int)(i % bZ), gy = by0 + (int)((i / bZ) % bY), gx = bx0 + (int)(i / ((int64_t)bZ * bY));
+    const int64_t d = ((int64_t)gx * Y + gy) * Z + gz;
+    f32x4 acc[V4];
+    f32x4* o = reinterpret_cast<f32x4*>(out + d * (4 * V4));
+#pragma unroll
+    for (int q = 0; q < V4; ++q) acc[q] = o[q];
+    const float inv = inv_count ? inv_count[d] : 1.f;
+    bool any = false;
+    for (int w = 0; w < nw; ++w) {
+      const int x = gx - starts[3 * w], y = gy - starts[3 * w + 1], z = gz - starts[3 * w + 2];
+      if ((unsigned)x >= (unsigned)rx || (unsigned)y >= (unsigned)ry || (unsigned)z >= (unsigned)rz) continue;
+      const int64_t v = ((int64_t)x * ry + y) * rz + z;
+      const float wgt = imp[v] * inv;
+      const f32x4* l = reinterpret_cast<const f32x4*>(logits + ((int64_t)w * wvox + v) * (4 * V4));
+#pragma unroll
+      for (int q = 0; q < V4; ++q) {
+        const f32x4 t = l[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * q + e < C) acc[q][e] += wgt * t[e];
+      }
+      any = true;
+    }
+    if (any) {
+#pragma unroll
+      for (int q = 0; q < V4; ++q) o[q] = acc[q];
+    }
   }
 }
 
@@ -203,6 +267,22 @@ extern "C" int ctseg_window_gather(const float* vol, int32_t Cin, int32_t X, int
   return 0;
 }
 
+extern "C" int ctseg_window_gather_batch(const float* vol, int32_t Cin, int32_t X, int32_t Y, int32_t Z, const int32_t* starts, int32_t nw,
+                                         int32_t rx, int32_t ry, int32_t rz, float cval, void* dst, int32_t dtype, int32_t ld,
+                                         void* stream) {
+  CTSEG_REQUIRE(vol && dst && starts && nw > 0 && nw < 65536 && Cin > 0 && ld >= Cin && X > 0 && Y > 0 && Z > 0 && rx > 0 && ry > 0 &&
+                    rz > 0, "window_gather_batch: bad arguments");
+  dim3 grid(nblocks((int64_t)rx * ry * rz * ld, 1024), (unsigned)nw);
+  if (dtype == CTSEG_F32)
+    hipLaunchKernelGGL(window_gather_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, vol, Cin, X, Y, Z, starts, rx, ry, rz,
+                       cval, (float*)dst, ld);
+  else
+    hipLaunchKernelGGL(window_gather_batch_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, vol, Cin, X, Y, Z, starts, rx,
+                       ry, rz, cval, (unsigned short*)dst, ld);
+  CTSEG_LAUNCH_CHECK("window_gather_batch");
+  return 0;
+}
+
 extern "C" int ctseg_window_blend(const float* logits, int32_t ld, int32_t C, int32_t rx, int32_t ry, int32_t rz, int32_t x0, int32_t y0,
                                   int32_t z0, const float* importance, const float* inv_count, float* out, int32_t X, int32_t Y, int32_t Z,
                                   int32_t out_ld, void* stream) {
@@ -211,5 +291,34 @@ extern "C" int ctseg_window_blend(const float* logits, int32_t ld, int32_t C, in
   hipLaunchKernelGGL(window_blend_kernel, dim3(nblocks((int64_t)rx * ry * rz * C)), dim3(256), 0, (hipStream_t)stream, logits, ld, C, rx, ry, rz,
                      x0, y0, z0, importance, inv_count, out, X, Y, Z, out_ld);
   CTSEG_LAUNCH_CHECK("window_blend");
+  return 0;
+}
+
+extern "C" int ctseg_window_blend_batch(const float* logits, int32_t ld, int32_t C, int32_t rx, int32_t ry, int32_t rz,
+                                        const int32_t* starts, int32_t nw, const float* importance, const float* inv_count,
+                                        float* out, int32_t X, int32_t Y, int32_t Z, int32_t out_ld, const int32_t* bbox,
+                                        void* stream) {
+  CTSEG_REQUIRE(logits && starts && importance && out && C > 0 && nw > 0 && X > 0 && Y > 0 && Z > 0 && rx > 0 && ry > 0 && rz > 0,
+                "window_blend_batch: bad arguments");
+  int b[6] = {0, 0, 0, X, Y, Z};
+  if (bbox != nullptr) {
+    for (int k = 0; k < 6; ++k) b[k] = bbox[k];
+    CTSEG_REQUIRE(b[0] >= 0 && b[1] >= 0 && b[2] >= 0 && b[3] > 0 && b[4] > 0 && b[5] > 0 && b[0] + b[3] <= X && b[1] + b[4] <= Y &&
+                      b[2] + b[5] <= Z, "window_blend_batch: bounding box outside the volume");
+  }
+  CTSEG_REQUIRE(ld == out_ld && ld % 4 == 0 && ld >= C && ld <= 16 && ((uintptr_t)logits % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                "window_blend_batch: rows must be 16-byte vectors with ld == out_ld <= 16 (got %d / %d)", ld, out_ld);
+  const unsigned nb = nblocks((int64_t)b[3] * b[4] * b[5], 16384);
+  hipStream_t st = (hipStream_t)stream;
+#define CTSEG_WBB(V) hipLaunchKernelGGL(window_blend_batch_kernel<V>, dim3(nb), dim3(256), 0, st, logits, C, rx, ry, rz, starts, nw, \
+                                        importance, inv_count, out, X, Y, Z, b[0], b[1], b[2], b[3], b[4], b[5])
+  switch (ld / 4) {
+    case 1: CTSEG_WBB(1); break;
+    case 2: CTSEG_WBB(2); break;
+    case 3: CTSEG_WBB(3); break;
+    default: CTSEG_WBB(4); break;
+  }
+#undef CTSEG_WBB
+  CTSEG_LAUNCH_CHECK("window_blend_batch");
   return 0;
 }

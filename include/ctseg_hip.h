@@ -222,9 +222,20 @@ int ctseg_resize3d_to_hwd(const void* image, int32_t image_dtype, const uint8_t*
  *          overlapping windows accumulate in stream order (deterministic). */
 int ctseg_window_gather(const float* vol, int32_t Cin, int32_t X, int32_t Y, int32_t Z, int32_t x0, int32_t y0, int32_t z0,
                         int32_t rx, int32_t ry, int32_t rz, float cval, void* dst, int32_t dtype, int32_t ld, void* stream);
+/* The same for nw windows in one launch: starts[nw][3] (device) = window origins, dst = [nw][rx*ry*rz][ld]. */
+int ctseg_window_gather_batch(const float* vol, int32_t Cin, int32_t X, int32_t Y, int32_t Z, const int32_t* starts, int32_t nw,
+                              int32_t rx, int32_t ry, int32_t rz, float cval, void* dst, int32_t dtype, int32_t ld, void* stream);
 int ctseg_window_blend(const float* logits, int32_t ld, int32_t C, int32_t rx, int32_t ry, int32_t rz, int32_t x0, int32_t y0,
                        int32_t z0, const float* importance, const float* inv_count, float* out, int32_t X, int32_t Y, int32_t Z,
                        int32_t out_ld, void* stream);
+/* The same accumulation for ALL nw windows of one forward batch in one launch (logits [nw][rx*ry*rz][ld], starts[nw][3] =
+ * window origins in output coordinates, on the device): per output voxel the covering windows are added in index order, i.e.
+ * exactly the sums of nw ctseg_window_blend calls in that order.  Rows are 16-byte vectors: ld == out_ld, a multiple of 4, <= 16.
+ * bbox (HOST pointer, 6 ints: origin x,y,z and extents, inside the volume; NULL = whole volume) bounds the voxels swept: it must
+ * contain every window of the batch clipped to the volume. */
+int ctseg_window_blend_batch(const float* logits, int32_t ld, int32_t C, int32_t rx, int32_t ry, int32_t rz, const int32_t* starts,
+                             int32_t nw, const float* importance, const float* inv_count, float* out, int32_t X, int32_t Y,
+                             int32_t Z, int32_t out_ld, const int32_t* bbox, void* stream);
 
 #ifdef __cplusplus
 }

@@ -345,6 +345,18 @@ class Emulator:
             sub = v[:, xs[ix][0]:xs[ix][-1] + 1, ys[iy][0]:ys[iy][-1] + 1, zs[iz][0]:zs[iz][-1] + 1]
             d[ix[0]:ix[-1] + 1, iy[0]:iy[-1] + 1, iz[0]:iz[-1] + 1, :Cin] = np.moveaxis(sub, 0, -1)
 
+    def window_gather_batch(self, vol, Cin, X, Y, Z, starts, nw, rx, ry, rz, cval, dst, dtype, ld):
+        st = mem(starts, nw * 3, np.int32).reshape(nw, 3)
+        for w in range(nw):
+            self.window_gather(vol, Cin, X, Y, Z, int(st[w, 0]), int(st[w, 1]), int(st[w, 2]), rx, ry, rz, cval,
+                               dst + w * rx * ry * rz * ld * 4, dtype, ld)
+
+    def window_blend_batch(self, logits, ld, C, rx, ry, rz, starts, nw, imp, inv_count, out, X, Y, Z, out_ld, bbox=None):
+        st = mem(starts, nw * 3, np.int32).reshape(nw, 3)
+        for w in range(nw):
+            self.window_blend(logits + w * rx * ry * rz * ld * 4, ld, C, rx, ry, rz, int(st[w, 0]), int(st[w, 1]), int(st[w, 2]), imp,
+                              inv_count, out, X, Y, Z, out_ld)
+
     def window_blend(self, logits, ld, C, rx, ry, rz, x0, y0, z0, imp, inv_count, out, X, Y, Z, out_ld):
         l = mem(logits, rx * ry * rz * ld).reshape(rx, ry, rz, ld)
         w = mem(imp, rx * ry * rz).reshape(rx, ry, rz)

@@ -135,3 +135,37 @@ def test_device_window_batch_changes_nothing_beyond_partial_sum_order(monkeypatc
     assert inferers.LAST_DEVICE_BATCH == 8          # all 8 windows of this volume in one forward
     assert (auto - exact).abs().max().item() < 2e-5 * exact.abs().max().item()
     assert torch.equal(auto.argmax(1), exact.argmax(1))
+
+
+@pytest.mark.gpu
+def test_batched_blend_equals_per_window_blend_bit_for_bit():
+    """ctseg_window_blend_batch (one output-centric launch) == the per-window ctseg_window_blend calls in the same order"""
+    from capstone_amd import _native as nat
+    g = torch.Generator().manual_seed(41)
+    X, Y, Z, C, ld = 20, 18, 14, 10, 12
+    roi = (12, 10, 8)
+    starts = [(0, 0, 0), (8, 0, 0), (0, 8, 6), (8, 8, 6), (4, 4, 3), (-2, 3, 0), (10, 9, 7)]     # overlapping, one hanging off the volume
+    nw = len(starts)
+    logits = torch.randn(nw, roi[0] * roi[1] * roi[2], ld, generator=g).cuda()
+    imp = (torch.rand(roi, generator=g) + 0.1).cuda()
+    inv = (torch.rand(X, Y, Z, generator=g) + 0.5).cuda()
+    a = torch.zeros(X, Y, Z, ld, device="cuda")
+    b = torch.zeros_like(a)
+    for w, (x0, y0, z0) in enumerate(starts):
+        nat.call("ctseg_window_blend", logits[w].data_ptr(), ld, C, *roi, x0, y0, z0, imp.data_ptr(), inv.data_ptr(), a.data_ptr(),
+                 X, Y, Z, ld)
+    st = torch.tensor(starts, dtype=torch.int32).cuda()
+    nat.call("ctseg_window_blend_batch", logits.data_ptr(), ld, C, *roi, st.data_ptr(), nw, imp.data_ptr(), inv.data_ptr(),
+             b.data_ptr(), X, Y, Z, ld, None)
+    torch.cuda.synchronize()
+    assert torch.equal(a[..., :C], b[..., :C])
+    # a second batch accumulates on top of the first, as successive forward batches of one volume do
+    for w, (x0, y0, z0) in enumerate(starts[:3]):
+        nat.call("ctseg_window_blend", logits[w].data_ptr(), ld, C, *roi, x0, y0, z0, imp.data_ptr(), inv.data_ptr(), a.data_ptr(),
+                 X, Y, Z, ld)
+    import ctypes
+    bbox = (ctypes.c_int32 * 6)(0, 0, 0, 20, 18, 14)      # windows 0..2 span x 0..19, y 0..17, z 0..13
+    nat.call("ctseg_window_blend_batch", logits.data_ptr(), ld, C, *roi, st.data_ptr(), 3, imp.data_ptr(), inv.data_ptr(),
+             b.data_ptr(), X, Y, Z, ld, bbox)
+    torch.cuda.synchronize()
+    assert torch.equal(a[..., :C], b[..., :C])
