@@ -261,17 +261,33 @@ class _Level:
         a = self.up0.emit_fwd(self.cat)
         return self.up1.emit_fwd(a, out=out, out_f32=out_f32)
 
-    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True):
+    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True, depth=0):
+        plan = self.plan
+        # The head's weight gradients (HBM-bound, 1.2 ms of side-stream work) are not queued beside the head's own HBM-bound
+        # input-gradient / norm-backward passes but when the backward reaches level `defer_to`, whose passes are MFMA-bound:
+        # same-box 12.48 -> 12.41 ms/step at 2, 12.44 at 1, 12.69 at 3 (the side stream's tail grows).
+        defer_to = int(os.environ.get("CTSEG_DEFER_HEAD_WGRAD", "2"))   # 0 = off
+        if self.is_top and defer_to > 0:
+            plan._defer = []
+        if depth == defer_to and depth > 0 and getattr(plan, "_stash", None):
+            plan._defer, plan._stash = plan._stash, None
+            plan.flush_deferred()
         if self.up1 is not None:
             g = self.up1.emit_bwd(g)
         gcat = self.up0.emit_bwd(g, split_at=self.c1)      # [d(skip) | d(sub output)], as two dense tensors where the kernel can
+        if self.is_top and defer_to > 0:
+            plan._stash, plan._defer = plan._defer, None     # only the head's weight gradients wait
         # d(skip) = gcat[:, :c1] + d(sub input).  The sum goes to a DENSE tensor (the addend is read from the concat-gradient
         # slice): the norm-backward passes of the down block then stream full cache lines instead of half of every line
         if os.environ.get("CTSEG_DENSE_SKIP_GRAD", "1") != "0":
-            gskip = self.sub.emit_bwd(gcat.slice(self.c1, self.c2), out=None, accumulate=gcat.slice(0, self.c1))
+            kw = {"depth": depth + 1} if isinstance(self.sub, _Level) else {}
+            gskip = self.sub.emit_bwd(gcat.slice(self.c1, self.c2), out=None, accumulate=gcat.slice(0, self.c1), **kw)
         else:
             self.sub.emit_bwd(gcat.slice(self.c1, self.c2), out=gcat.slice(0, self.c1), accumulate=True)
             gskip = gcat.slice(0, self.c1)
+        if self.is_top and getattr(plan, "_stash", None):     # never flushed below (fewer levels than asked for)
+            plan._defer, plan._stash = plan._stash, None
+            plan.flush_deferred()
         return self.down.emit_bwd(gskip, out=out, accumulate=accumulate, need_dx=need_dx)
 
 
@@ -284,6 +300,7 @@ class Plan:
         self.need_input_grad = False
         self.packer = Packer(self)
         self.fwd, self.bwd, self._cur = [], [], None
+        self._defer = None
         self._keep = []
         self.ready_marks = []          # (program index in bwd, flat offset end) for gradient all-reduce overlap
         self.shape = (N, X, Y, Z)
@@ -312,7 +329,11 @@ class Plan:
             else:
                 conv.append(a)
         self._keep.append(keep)
-        self._cur.append((name, fn, tuple(conv)))
+        op = (name, fn, tuple(conv))
+        if self._defer is not None and self._cur is self.bwd and name in self.SIDE_OPS:
+            self._defer.append(op)        # head weight gradients: queued later, beside the MFMA-bound deep levels
+        else:
+            self._cur.append(op)
 
     def emit_colsum(self, x, out_ptr):
         rows = x.dims[0] * x.S
@@ -322,7 +343,20 @@ class Plan:
 
     def grads_ready(self, params):
         if self._cur is self.bwd:
-            self.ready_marks.append((len(self.bwd), [self.store.off(p) for p in params if p is not None]))
+            offs = [self.store.off(p) for p in params if p is not None]
+            if self._defer is not None:
+                self._defer.append(("ready", offs))
+            else:
+                self.ready_marks.append((len(self.bwd), offs))
+
+    def flush_deferred(self):
+        """append the deferred side-stream ops (and their gradient-readiness marks) to the backward program"""
+        ops, self._defer = self._defer, None
+        for op in ops or ():
+            if op[0] == "ready":
+                self.ready_marks.append((len(self.bwd), op[1]))
+            else:
+                self.bwd.append(op)
 
     # ---- running ----
     @staticmethod
