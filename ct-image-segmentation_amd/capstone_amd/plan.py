@@ -456,8 +456,17 @@ class Plan:
         bounds = sorted(set(self._side_edges) | {i for i in hooks if 0 <= i <= n})
         for a, b in zip(bounds[:-1], bounds[1:]):
             if a in hooks:
-                join()
-                hooks[a]()
+                # the hook (a gradient all-reduce) needs what BOTH streams have produced so far, but nothing on the main stream
+                # needs the hook: it is issued from the side stream (which first waits for the main stream's position), so the
+                # main stream never stalls on the weight gradients still queued there
+                ev = self._side_ev.get(("hook", a))
+                if ev is None:
+                    ev = self._side_ev[("hook", a)] = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    hooks[a]()
+                busy = True
             if self.bwd[a][0] in self.SIDE_OPS:
                 ev = self._side_ev.get(a)
                 if ev is None:
