@@ -182,6 +182,7 @@ void launch_conv_halo(ConvKArgs& a, int dtype, hipStream_t st);
 // 8-class stride-2 "up" pass with <= 16 output channels (conv_up_halo.hip): one input tile for all parity classes
 bool conv_up_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_up_tiles(const ConvKArgs& a);
+int conv_up_slots(const ConvKArgs& a);   // InstanceNorm partial slots per sample (= workgroups)
 void launch_conv_up(ConvKArgs& a, hipStream_t st);
 // single-channel 3x3x3 stride-2 stem (conv_stem.hip)
 bool conv_stem_eligible(const ConvKArgs& a, int dtype, int nclass);

@@ -389,7 +389,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
     CTSEG_REQUIRE(d->stats_tile0 + conv_stem_slots(a) <= d->stats_tiles && d->stats_ld >= ((d->Cn + 15) / 16) * 16,
                   "conv_igemm: stats partial layout (stem pass)");
   } else if (d->stats && up) {
-    CTSEG_REQUIRE(d->stats_tile0 + conv_up_tiles(a) <= d->stats_tiles && d->stats_ld >= 16, "conv_igemm: stats partial layout (up pass)");
+    CTSEG_REQUIRE(d->stats_tile0 + conv_up_slots(a) <= d->stats_tiles && d->stats_ld >= 16, "conv_igemm: stats partial layout (up pass)");
   } else if (d->stats) {
     const int bm = tile_rows_for(a, d->dtype, smallc, d->nclass);
     const int tiles = halo ? conv_halo_slots(a, d->dtype) : (a.rows + bm - 1) / bm;
@@ -453,7 +453,7 @@ extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
   fill_args(d, a);
   if (conv_halo_eligible(a, d->dtype, d->nclass)) return conv_halo_slots(a, d->dtype);
   a.out_f32 = d->out_f32; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo;
-  if (conv_up_eligible(a, d->dtype, d->nclass)) return conv_up_tiles(a);
+  if (conv_up_eligible(a, d->dtype, d->nclass)) return conv_up_slots(a);
   a.add = (const char*)d->add; a.o_ld = d->o_ld;
   if (conv_stem_eligible(a, d->dtype, d->nclass)) return conv_stem_slots(a);
   if (conv_halo_sw_eligible(a, d->dtype, d->nclass)) return conv_halo_sw_slots(a);

@@ -124,15 +124,48 @@ __global__ __launch_bounds__(512) void conv_up_halo_kernel(const ConvKArgs P, in
   for (int e = 0; e < 4; ++e) bias[e] = (P.bias != nullptr && 4 * q4 + e < P.Cn) ? P.bias[4 * q4 + e] : 0.f;
   const int ch = 4 * q4;
 
+  // InstanceNorm partial sums stay in registers across the workgroup's tiles and are written once per (workgroup, sample):
+  // one partial slot per workgroup instead of one per tile (12 288 tiles per sample at 256x256x24 -> 256 slots: no per-tile
+  // shuffles / barrier, and the finalize that sits between this pass and its norm pass reads 48x fewer rows)
+  float wsum[4] = {0.f, 0.f, 0.f, 0.f}, wsq[4] = {0.f, 0.f, 0.f, 0.f};
+  int stat_n = -1;
+  auto flush_stats = [&](int n) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = wsum[e], b = wsq[e];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+      if (r16 == 0) {
+        sStats[(wave8 * 2 + 0) * 16 + 4 * q4 + e] = a;
+        sStats[(wave8 * 2 + 1) * 16 + 4 * q4 + e] = b;
+      }
+      wsum[e] = 0.f;
+      wsq[e] = 0.f;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, c = tid & 15;
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += sStats[(w * 2 + which) * 16 + c];
+      const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + blockIdx.x;
+      P.stats[(slot_t * 2 + which) * P.stats_ld + c] = a;
+    }
+    __syncthreads();
+  };
+
   auto compute_tile = [&](int t) {
     int n, x0, y0, z0;
     tile_origin(t, n, x0, y0, z0);
+    if (P.stats != nullptr && n != stat_n) {
+      if (stat_n >= 0) flush_stats(stat_n);
+      stat_n = n;
+    }
     const int64_t vb = (((int64_t)n * P.Xo + 2 * x0) * P.Yo + 2 * y0) * P.Zo + 2 * z0;
     const bool xok = x0 + wave < P.Xr, zok = z0 + pz < P.Zr;
     bool rv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) rv[i] = xok && zok && (y0 + 2 * i + pdy < P.Yr);
-    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
     // one parity class, tap count known at compile time (class c has 2^popcount(c) taps — checked by conv_up_eligible): the
     // fully unrolled body lets the scheduler run the LDS operand reads of the next taps under the MFMAs of the current one,
     // which matters here because the 134 KB LDS image leaves a single wave per SIMD
@@ -167,7 +200,7 @@ __global__ __launch_bounds__(512) void conv_up_halo_kernel(const ConvKArgs P, in
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = acc[i][e] + bias[e];
-          if (rv[i]) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+          if (rv[i]) { wsum[e] += v[e]; wsq[e] += v[e] * v[e]; }
         }
         if (rv[i] && ch < P.Cn_store) {
           if (ab != nullptr) {
@@ -193,27 +226,6 @@ __global__ __launch_bounds__(512) void conv_up_halo_kernel(const ConvKArgs P, in
       do_class(integral_constant<int, 4>{}, 5);
       do_class(integral_constant<int, 4>{}, 6);
       do_class(integral_constant<int, 2>{}, 4);
-    }
-    if (P.stats != nullptr) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a = ssum[e], b = ssq[e];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        if (r16 == 0) {
-          sStats[(wave8 * 2 + 0) * 16 + 4 * q4 + e] = a;
-          sStats[(wave8 * 2 + 1) * 16 + 4 * q4 + e] = b;
-        }
-      }
-      __syncthreads();
-      if (tid < 32) {
-        const int which = tid >> 4, c = tid & 15;
-        float a = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) a += sStats[(w * 2 + which) * 16 + c];
-        const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + (t - n * tiles_per_sample);
-        P.stats[(slot_t * 2 + which) * P.stats_ld + c] = a;
-      }
     }
   };
 
@@ -242,6 +254,7 @@ __global__ __launch_bounds__(512) void conv_up_halo_kernel(const ConvKArgs P, in
     if (tn < last) sstore();
     __syncthreads();
   }
+  if (P.stats != nullptr && stat_n >= 0) flush_stats(stat_n);
 }
 
 bool conv_up_eligible(const ConvKArgs& a, int dtype, int nclass) {
@@ -268,13 +281,20 @@ bool conv_up_eligible(const ConvKArgs& a, int dtype, int nclass) {
 
 int conv_up_tiles(const ConvKArgs& a) { return ((a.Xr + 3) / 4) * ((a.Yr + 7) / 8) * ((a.Zr + 7) / 8); }
 
+static int up_grid(const ConvKArgs& a) {
+  const int total = conv_up_tiles(a) * a.N;
+  const int gx = (a.Cg * 2 == 128) ? 256 : 512;
+  return gx < total ? gx : total;
+}
+// InstanceNorm partial slots per sample: one per workgroup
+int conv_up_slots(const ConvKArgs& a) { return up_grid(a); }
+
 void launch_conv_up(ConvKArgs& a, hipStream_t st) {
   const int tyn = (a.Yr + 7) / 8, tzn = (a.Zr + 7) / 8;
   a.tiles = conv_up_tiles(a);
   const int total = a.tiles * a.N;
   const int vb = a.Cg * 2;
-  int gx = (vb == 128) ? 256 : 512;
-  if (gx > total) gx = total;
+  const int gx = up_grid(a);
   if (vb == 128) hipLaunchKernelGGL((conv_up_halo_kernel<128>), dim3(gx), dim3(512), 0, st, a, total, tyn, tzn);
   else hipLaunchKernelGGL((conv_up_halo_kernel<64>), dim3(gx), dim3(512), 0, st, a, total, tyn, tzn);
 }
