@@ -85,9 +85,10 @@ _SIGS = {
     "ctseg_instnorm_prelu_bwd_reduce": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     "ctseg_instnorm_prelu_bwd_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
     "ctseg_instnorm_prelu_dalpha": (C.c_int, [_vp, _i32, _vp, _vp]),
-    "ctseg_instnorm_prelu_bwd_apply": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
+    "ctseg_instnorm_prelu_bwd_apply": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i64, _i32,
+                                                 _vp, _i32, _vp, _vp]),
     "ctseg_instnorm_prelu_bwd_apply_colsum": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i64, _i32,
-                                                        _vp, _i32, _vp, _vp]),
+                                                        _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ctseg_colsum": (C.c_int, [_i32, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp]),
     "ctseg_squash_masks": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "ctseg_seg_loss": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),

@@ -66,17 +66,19 @@ class _NormAct:
         a_ptr = plan.store.p_ptr(self.alpha)
         plan.emit("ctseg_instnorm_prelu_bwd_reduce", plan.dt, g.ptr(), g.ld, y.ptr(), y.ld, self.mr.data_ptr(), a_ptr,
                   part.data_ptr(), P, ld, N, S, C, keep=(g, part))
-        da_part = torch.zeros(N * C + 1, dtype=torch.float64, device=plan.device)     # + completion counter
+        da_part = torch.zeros(N * C + 1, dtype=torch.float64, device=plan.device)
+        # the slope-gradient sum over da_part rides on the apply pass below (one of its workgroups; no launch, no atomics)
         plan.emit("ctseg_instnorm_prelu_bwd_finalize", part.data_ptr(), N, P, ld, C, float(S), da_part.data_ptr(), sums.data_ptr(),
-                  plan.store.g_ptr(self.alpha), keep=(sums, da_part))
+                  None, keep=(sums, da_part))
         args = (plan.dt, g.ptr(), g.ld, y.ptr(), y.ld, self.mr.data_ptr(), a_ptr, sums.data_ptr(), dy_out.ptr(), dy_out.ld,
                 g_copy.ptr() if g_copy is not None else None, g_copy.ld if g_copy is not None else 0, N, S, C)
+        slope = (da_part.data_ptr(), N * C, plan.store.g_ptr(self.alpha))
         if colsum_out is None:
-            plan.emit("ctseg_instnorm_prelu_bwd_apply", *args, keep=(dy_out, g_copy))
+            plan.emit("ctseg_instnorm_prelu_bwd_apply", *args, *slope, keep=(dy_out, g_copy))
         else:
             p_cap = N * 512
             cs_part = torch.zeros((p_cap, rup(C, nat.epc(plan.dt))), dtype=torch.float32, device=plan.device)
-            plan.emit("ctseg_instnorm_prelu_bwd_apply_colsum", *args, cs_part.data_ptr(), p_cap, colsum_out,
+            plan.emit("ctseg_instnorm_prelu_bwd_apply_colsum", *args, cs_part.data_ptr(), p_cap, colsum_out, *slope,
                       keep=(dy_out, g_copy, cs_part))
         return dy_out
 

@@ -285,12 +285,24 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
                                                                         const float* __restrict__ sums, char* __restrict__ dy,
                                                                         int dy_ld, char* __restrict__ g_copy, int g_copy_ld,
                                                                         int64_t S, int C, int Cv, float* __restrict__ cs_part,
-                                                                        int pld) {
+                                                                        int pld, const double* __restrict__ da_part, int n_da,
+                                                                        float* __restrict__ dalpha) {
   constexpr int SZ = TT<T>::SZ;   // EPC: elements per chunk (a row is Cv chunks of EPC elements)
   extern __shared__ float s_tab[];  // [C][4]: mean, rstd, s1, s2  (+ [256][EPC] column-sum scratch when COLSUM)
   float cs[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) cs[e] = 0.f;
+  // PReLU slope gradient = fixed-order sum of the finalize pass's per-(n, c) terms: one block of this launch does it on the
+  // side (no launch of its own, no atomics -- a same-address counter in the finalize cost ~40 ns per block, 20 us at C = 256)
+  if (da_part != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+    __shared__ double s_da[4];
+    double a = 0.0;
+    for (int k = threadIdx.x; k < n_da; k += 256) a += da_part[k];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) s_da[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) dalpha[0] = (float)(((s_da[0] + s_da[1]) + s_da[2]) + s_da[3]);
+  }
   // the reduce pass that precedes this one streamed (g, y) front to back: walk BACKWARDS (last sample first, last voxel
   // first) so the most recently read part of both tensors is re-read while it still sits in L2 / Infinity Cache
   const int n = gridDim.y - 1 - blockIdx.y;
@@ -547,8 +559,10 @@ extern "C" int ctseg_instnorm_prelu_dalpha(const double* scratch, int32_t NC, fl
 
 static int bwd_apply_launch(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld, const float* mean_rstd,
                             const float* alpha, const float* sums, void* dy, int32_t dy_ld, void* g_copy, int32_t g_copy_ld, int32_t N,
-                            int64_t S, int32_t C, float* cs_part, int32_t P_cap, float* cs_out, void* stream) {
+                            int64_t S, int32_t C, float* cs_part, int32_t P_cap, float* cs_out, const double* da_part, int32_t n_da,
+                            float* dalpha, void* stream) {
   CTSEG_REQUIRE(g && y && mean_rstd && alpha && sums && dy && N > 0, "instnorm_prelu_bwd_apply: bad arguments");
+  CTSEG_REQUIRE(da_part == nullptr || (dalpha != nullptr && n_da > 0), "instnorm_prelu_bwd_apply: slope-gradient arguments");
   CHECK_CL_HALF(dtype, C, g_ld, y_ld, dy_ld, g_copy ? g_copy_ld : dy_ld);
   int gx = ew_blocks_for(S * Cv, Cv);
   const bool colsum = cs_part != nullptr;
@@ -567,7 +581,7 @@ static int bwd_apply_launch(int32_t dtype, const void* g, int32_t g_ld, const vo
   hipStream_t st = (hipStream_t)stream;
 #define CTSEG_APPLY(T, EP, CS)                                                                                                      \
   hipLaunchKernelGGL((instnorm_prelu_bwd_apply_kernel<T, EP, CS>), grid, dim3(256), sh, st, (const char*)g, g_ld, (const char*)y, y_ld, \
-                     mean_rstd, alpha, sums, (char*)dy, dy_ld, (char*)g_copy, g_copy_ld, S, C, Cv, cs_part, pld)
+                     mean_rstd, alpha, sums, (char*)dy, dy_ld, (char*)g_copy, g_copy_ld, S, C, Cv, cs_part, pld, da_part, n_da, dalpha)
   if (dtype == CTSEG_F32) { if (colsum) CTSEG_APPLY(float, 4, true); else CTSEG_APPLY(float, 4, false); }
   else if (EPC_ == 8) { if (colsum) CTSEG_APPLY(BF16, 8, true); else CTSEG_APPLY(BF16, 8, false); }
   else { if (colsum) CTSEG_APPLY(BF16, 4, true); else CTSEG_APPLY(BF16, 4, false); }
@@ -580,18 +594,19 @@ static int bwd_apply_launch(int32_t dtype, const void* g, int32_t g_ld, const vo
 extern "C" int ctseg_instnorm_prelu_bwd_apply(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
                                               const float* mean_rstd, const float* alpha, const float* sums, void* dy,
                                               int32_t dy_ld, void* g_copy, int32_t g_copy_ld, int32_t N, int64_t S, int32_t C,
-                                              void* stream) {
+                                              const double* da_part, int32_t n_da, float* dalpha, void* stream) {
   return bwd_apply_launch(dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C, nullptr, 0, nullptr,
-                          stream);
+                          da_part, n_da, dalpha, stream);
 }
 
 extern "C" int ctseg_instnorm_prelu_bwd_apply_colsum(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
                                                      const float* mean_rstd, const float* alpha, const float* sums, void* dy,
                                                      int32_t dy_ld, void* g_copy, int32_t g_copy_ld, int32_t N, int64_t S, int32_t C,
-                                                     float* colsum_partials, int32_t P_cap, float* colsum_out, void* stream) {
+                                                     float* colsum_partials, int32_t P_cap, float* colsum_out,
+                                                     const double* da_part, int32_t n_da, float* dalpha, void* stream) {
   CTSEG_REQUIRE(colsum_partials != nullptr, "instnorm_prelu_bwd_apply_colsum: partial buffer");
   return bwd_apply_launch(dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C, colsum_partials,
-                          P_cap, colsum_out, stream);
+                          P_cap, colsum_out, da_part, n_da, dalpha, stream);
 }
 
 extern "C" int ctseg_colsum(int32_t dtype, const void* x, int32_t ld, int64_t rows, int32_t C, float* partials, int32_t P,

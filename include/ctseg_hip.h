@@ -145,17 +145,21 @@ int ctseg_instnorm_prelu_bwd_reduce(int32_t dtype, const void* g, int32_t g_ld, 
 int ctseg_instnorm_prelu_bwd_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t C, double S,
                                       double* scratch, float* sums, float* dalpha, void* stream);
 int ctseg_instnorm_prelu_dalpha(const double* scratch, int32_t NC, float* dalpha, void* stream);
-/* backward, pass 2: dy = rstd*(dxhat - s1 - xhat*s2); optionally also copies g to g_copy (fused residual hand-off) */
+/* backward, pass 2: dy = rstd*(dxhat - s1 - xhat*s2); optionally also copies g to g_copy (fused residual hand-off).
+ * da_part != NULL: one workgroup of the launch also writes dalpha = fixed-order sum of da_part[0 .. n_da) (the per-(n,c) slope
+ * terms ctseg_instnorm_prelu_bwd_finalize left in its scratch) -- the PReLU slope gradient without a launch of its own. */
 int ctseg_instnorm_prelu_bwd_apply(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
                                    const float* mean_rstd, const float* alpha, const float* sums, void* dy, int32_t dy_ld,
-                                   void* g_copy, int32_t g_copy_ld, int32_t N, int64_t S, int32_t C, void* stream);
+                                   void* g_copy, int32_t g_copy_ld, int32_t N, int64_t S, int32_t C, const double* da_part,
+                                   int32_t n_da, float* dalpha, void* stream);
 /* Same pass, plus the column sums of dy over all N*S voxels -> colsum_out[C] (fp32): the bias gradient of the ConvTranspose3d
  * whose output this norm consumed (autograd: dOut.sum over voxels), without a second trip over dy.  colsum_partials: scratch of
  * P_cap rows x roundup(C, chunk) floats (P_cap >= N; a few thousand rows keep the whole chip busy); fixed-order sums. */
 int ctseg_instnorm_prelu_bwd_apply_colsum(int32_t dtype, const void* g, int32_t g_ld, const void* y, int32_t y_ld,
                                           const float* mean_rstd, const float* alpha, const float* sums, void* dy, int32_t dy_ld,
                                           void* g_copy, int32_t g_copy_ld, int32_t N, int64_t S, int32_t C, float* colsum_partials,
-                                          int32_t P_cap, float* colsum_out, void* stream);
+                                          int32_t P_cap, float* colsum_out, const double* da_part, int32_t n_da, float* dalpha,
+                                          void* stream);
 
 /* out[c] = sum over rows of x[row][c] (bias gradient of nn.ConvTranspose3d); partials [P][roundup(C,chunk)] fp32 scratch */
 int ctseg_colsum(int32_t dtype, const void* x, int32_t ld, int64_t rows, int32_t C, float* partials, int32_t P, float* out,

@@ -181,7 +181,10 @@ class Emulator:
     def instnorm_prelu_dalpha(self, scratch, NC, dalpha):
         mem(dalpha, 1)[0] = mem(scratch, NC, np.float64).sum()
 
-    def instnorm_prelu_bwd_apply(self, dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C):
+    def instnorm_prelu_bwd_apply(self, dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C,
+                                 da_part=None, n_da=0, dalpha=None):
+        if da_part:
+            mem(dalpha, 1)[0] = mem(da_part, n_da, np.float64).sum()
         xh, rstd = self._xhat(y, y_ld, mean_rstd, N, S, C)
         gv = self._rows(g, N, S, C, g_ld)
         a = mem(alpha, 1)[0]
@@ -195,8 +198,9 @@ class Emulator:
             self._rows(g_copy, N, S, Cp, g_copy_ld)[:] = self._rows(g, N, S, Cp, g_ld)
 
     def instnorm_prelu_bwd_apply_colsum(self, dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C,
-                                        cs_part, p_cap, cs_out):
-        self.instnorm_prelu_bwd_apply(dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C)
+                                        cs_part, p_cap, cs_out, da_part=None, n_da=0, dalpha=None):
+        self.instnorm_prelu_bwd_apply(dtype, g, g_ld, y, y_ld, mean_rstd, alpha, sums, dy, dy_ld, g_copy, g_copy_ld, N, S, C,
+                                      da_part, n_da, dalpha)
         mem(cs_out, C)[:] = self._rows(dy, N, S, C, dy_ld).reshape(-1, C).sum(0, dtype=np.float64)
 
     def colsum(self, dtype, x, ld, rows, C, partials, P, out):
