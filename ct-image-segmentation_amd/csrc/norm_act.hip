@@ -17,12 +17,14 @@ constexpr int FIN_GROUPS = 64;
 __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __restrict__ part, int P, int ld, int col0, int C,
                                                                 double count, double eps, double* __restrict__ scratch,
                                                                 unsigned int* __restrict__ counter, float* __restrict__ mean_rstd) {
+  // gridDim.x = groups in use (<= FIN_GROUPS; few partial rows -> few groups, so the second level has less to walk)
+  const int G = gridDim.x;
   // This launch sits between every conv and its norm pass with nothing to overlap it: what counts is the length of its
   // dependent-load chains, so both levels spread their sums over all 256 threads.
   __shared__ int s_last;
   __shared__ double s_sub[256];
   const int g = blockIdx.x, n = blockIdx.y, rowlen = 2 * ld, t = threadIdx.x;
-  const int F = (P + FIN_GROUPS - 1) / FIN_GROUPS;
+  const int F = (P + G - 1) / G;
   const int p0 = g * F, p1 = (p0 + F < P) ? p0 + F : P;
   // level 1: nj columns x R row lanes; lane r sums rows p0 + r, p0 + r + R, ...; the R sub-sums combine in lane order
   const int nj = rowlen < 256 ? rowlen : 256, R = 256 / nj;
@@ -44,19 +46,19 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
   }
   __threadfence();
   __syncthreads();
-  if (t == 0) s_last = (atomicAdd(&counter[n], 1u) == (unsigned)(FIN_GROUPS - 1));
+  if (t == 0) s_last = (atomicAdd(&counter[n], 1u) == (unsigned)(G - 1));
   __syncthreads();
   if (!s_last) return;
   __threadfence();
   // level 2 (last block of the sample): L lanes per channel, lane l sums groups l, l + L, ...; xor butterfly over the L lanes
   int L = 1;
-  while (L * 2 <= FIN_GROUPS && L * 2 * C <= 256) L *= 2;
+  while (L * 2 <= G && L * 2 * C <= 256) L *= 2;
   const int per = 256 / L;                       // channels per sweep
   for (int cb = 0; cb < C; cb += per) {
     const int c = cb + t / L, l = t & (L - 1);
     double sm = 0.0, q = 0.0;
     if (c < C)
-      for (int gg = l; gg < FIN_GROUPS; gg += L) {
+      for (int gg = l; gg < G; gg += L) {
         sm += __builtin_nontemporal_load(&scratch[((int64_t)n * FIN_GROUPS + gg) * rowlen + col0 + c]);
         q += __builtin_nontemporal_load(&scratch[((int64_t)n * FIN_GROUPS + gg) * rowlen + ld + col0 + c]);
       }
@@ -493,7 +495,9 @@ extern "C" int ctseg_instnorm_finalize(const float* partials, int32_t N, int32_t
   hipStream_t st = (hipStream_t)stream;
   // scratch: N * FIN_GROUPS * 2 * ld doubles of group sums, followed by N zero-initialised counters (one double slot each)
   unsigned int* counter = reinterpret_cast<unsigned int*>(scratch + (int64_t)N * FIN_GROUPS * 2 * ld);
-  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(FIN_GROUPS, N), dim3(256), 0, st, partials, P, ld, col0, C, count, eps, scratch,
+  int groups = P / 8;                      // >= 8 partial rows per first-level group
+  groups = groups < 1 ? 1 : (groups > FIN_GROUPS ? FIN_GROUPS : groups);
+  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(groups, N), dim3(256), 0, st, partials, P, ld, col0, C, count, eps, scratch,
                      counter, mean_rstd);
   CTSEG_LAUNCH_CHECK("instnorm_finalize");
   return 0;
