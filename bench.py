@@ -87,14 +87,36 @@ def cpu_baseline(shape, threads):
                       f"(= {frac:.3f} of a 512x512x48 volume), {dt:.1f} s on {threads} threads"}
 
 
+def fp32_line(model, batch, steps):
+    """the same workload in fp32 storage (v_mfma_f32_16x16x4_f32: the reference's own arithmetic), a few steps, N=1"""
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    dev = batch[0].device
+    # (the bf16 model's buffers stay allocated: both plans together are a fraction of the 288 GB)
+    torch.manual_seed(SEED)
+    m = BaseUNet3D(filters=list(FILTERS), loss_fx=["CrossEntropy"], precision="fp32", batch_size=batch[0].shape[0]).to(dev)
+    for _ in range(2):
+        m.fit_step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = m.fit_step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"dtype": "f32", "steps": steps, "ms_per_step": dt * 1e3, "volumes_per_s": batch[0].shape[0] / dt,
+            "loss_last_step": float(loss.item())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)     # ~2.4 s of timed GPU work at 12 ms/step: visible to a busy sampler
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", type=int, nargs=4, default=[2, 512, 512, 48], metavar=("B", "H", "W", "D"))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp32-steps", type=int, default=5,
+                    help="N=1 only: also time this many steps of the same workload in fp32 storage (the reference's own "
+                         "arithmetic) after the main measurement; reported under config.fp32 (0 = skip)")
     ap.add_argument("--cpu-shape", type=int, nargs=4, default=[1, 512, 512, 48])   # one volume = half a batch: ~10 s on 16 host threads
     args = ap.parse_args()
 
@@ -110,10 +132,12 @@ def main():
     torch.manual_seed(SEED)
     model = BaseUNet3D(filters=list(FILTERS), loss_fx=["CrossEntropy"], precision=args.precision, batch_size=B).to(dev)
     batch = synthetic_batch(B, H, W, D, dev, SEED + rank)
-    model.fit_step(batch)                     # builds the plan (untimed, counted as warmup 0)
     if world > 1:
+        # replicas BEFORE the first optimizer step: rank 0's weights (and the still-empty Adam state) everywhere, then every
+        # step applies the same update to the same mean gradient
+        model.unet.engine().ensure(dev)
         cdist.attach(model)
-    for _ in range(max(args.warmup - 1, 0)):
+    for _ in range(max(args.warmup, 1)):      # the first one builds the plan
         model.fit_step(batch)
 
     eng = model.unet.engine()
@@ -154,37 +178,54 @@ def main():
         elapsed = float(t.item())
     loss_v = float(loss.item())
 
+    baseline_shape = (B, H, W, D) == (2, 512, 512, 48)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        out = {"metric": "CT volumes/sec training (512x512x48, bs=2/GPU)", "value": world * B * args.steps / elapsed,
+        out = {"metric": f"CT volumes/sec training ({H}x{W}x{D}, bs={B}/GPU)", "value": world * B * args.steps / elapsed,
                "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": f"3D U-Net (MONAI UNet, channels 32-64-128-256, 2 res units) training step on "
-                                      f"{B}x1x{H}x{W}x{D} synthetic CT volumes per GPU (BASELINE.json configs[2]"
-                                      f"{'' if world == 1 else '/[3]'}), CrossEntropy + Dice metric + Adam",
+                                      f"{B}x1x{H}x{W}x{D} synthetic CT volumes per GPU ("
+                                      + (f"BASELINE.json configs[2]{'' if world == 1 else '/[3]'}" if baseline_shape else
+                                         "NOT the BASELINE.json shape 2x512x512x48")
+                                      + "), CrossEntropy + Dice metric + Adam",
                           "global_batch": world * B, "parallelism": f"dp{world}", "loss_last_step": loss_v}}
         if ev:
             raw = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)
             ovh = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev)
-            kms = raw - ovh     # launch duration = bracketed interval minus the empty-bracket interval measured beside it
+            # launch duration = the bracketed interval as measured: that is the figure the rocprofv3 per-dispatch average of the
+            # same command agrees with (r01: 148.1 us vs 148.5 us bracket).  The interval of an empty bracket recorded right
+            # behind it (what a pair of event records costs by itself) is reported beside it, not subtracted.
+            kms = raw
             n_, x_, y_, z_ = B, H // 8, W // 8, D // 8
             flop = 2.0 * n_ * x_ * y_ * z_ * 256 * 256 * 27
             peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
             ach = flop / (kms * 1e-3) / 1e12
             traffic = None     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this very kernel
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_bottleneck.json")
+            pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("pmc_bottleneck.json"))
+            pmc = os.path.join(ROOT, "profiles", pmc[-1]) if pmc else ""
             if args.precision == "bf16" and (B, H, W, D) == (2, 512, 512, 48) and os.path.exists(pmc):
                 traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": traffic, "kernel": "conv_igemm_ring_kernel (192x256 tile, bf16) encoder-bottleneck Conv3d 256->256 k3",
-                               "launch_ms": kms, "launch_ms_bracket": raw, "event_pair_ms": ovh, "flop_per_launch": flop}
+                               "launch_ms": kms, "launch_ms_minus_event_pair": raw - ovh, "event_pair_ms": ovh,
+                               "flop_per_launch": flop, "launches_timed": len(ev)}
+            if baseline_shape:
+                # the whole step against SURVEY.md §8(d)'s per-layer roofline: sum over the conv layers of
+                # max(FLOP / 2.5 PFLOP/s, bytes / 6.29 TB/s), forward 0.89 ms, training step ~2.7 ms
+                step_flop, step_roof_ms = 4092e9, 2.7
+                out["roofline"]["step"] = {"flop": step_flop, "ms": ms, "tflops": step_flop / (ms * 1e-3) / 1e12,
+                                           "frac_of_mfma_peak": step_flop / (ms * 1e-3) / 1e12 / peak,
+                                           "per_layer_roofline_ms": step_roof_ms, "frac_of_per_layer_roofline": step_roof_ms / ms}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 ncpu = len(os.sched_getaffinity(0))
             except AttributeError:
                 ncpu = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(tuple(args.cpu_shape), max(1, min(ncpu, 16)))
+        if world == 1 and args.fp32_steps > 0 and args.precision == "bf16":
+            out["config"]["fp32"] = fp32_line(model, batch, args.fp32_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

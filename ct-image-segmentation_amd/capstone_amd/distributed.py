@@ -55,6 +55,7 @@ def split_points(ready_marks, sizes, n_total, first_fraction=0.6):
 class GradAllReducer:
     def __init__(self, flat_g, n, ready_marks=None, sizes=None, group=None, always=False):
         self.flat_g, self.n, self.group = flat_g, n, group
+        self.sizes = sizes
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # always=True issues the collectives on a one-rank group too (a one-GPU box can then drive RCCL's stream
         # hand-offs against the two-stream backward; the sums are the identity there)
@@ -66,11 +67,21 @@ class GradAllReducer:
         if hi > lo and self.active:
             self.works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def points_for(self, plan):
+        """split points of THIS plan's backward program (another batch shape, or the 16-wide fallback of the narrow-row layout,
+        records a different program: its readiness marks sit at other indices), cached on the plan"""
+        if plan is None or self.sizes is None:
+            return self.points
+        pts = getattr(plan, "_ddp_points", None)
+        if pts is None:
+            pts = plan._ddp_points = split_points(plan.ready_marks, self.sizes, self.n) if plan.ready_marks else []
+        return pts
+
     def hooks(self, plan=None):
         """{backward program index: callable} — fired by Plan.backward between ops"""
         self.works, self.sent = [], 0
         h = {}
-        for idx, end in self.points:
+        for idx, end in self.points_for(plan):
             def fire(end=end):
                 self._launch(self.sent, end)
                 self.sent = end
@@ -93,14 +104,24 @@ def broadcast_params(flat_p, group=None):
 
 
 def attach(module, group=None, always=False):
-    """make a BaseUNet3D data-parallel: identical weights on every rank + overlapped gradient all-reduce."""
+    """make a BaseUNet3D data-parallel: identical replicas on every rank + overlapped gradient all-reduce.
+
+    A replica is the weights AND the optimizer state ("identical replicated weights + Adam state"; Lightning's
+    DDP gets there by constructing every rank from the same seed before any step): rank 0's flat parameter buffer, both Adam
+    moment buffers and the step count are broadcast, so attach() may be called at any point — before the first step (the
+    moments are then zeros everywhere) or after rank-local warm-up steps — and the replicas leave it bit-identical.
+    Needs ``engine.ensure(device)`` (or any forward) first so the flat buffers exist."""
     eng = module.unet.engine()
     st = eng.store
-    assert st is not None, "run one forward (or engine.ensure(device)) before attach()"
-    broadcast_params(st.flat_p, group)
+    assert st is not None, "run engine.ensure(device) (or one forward) before attach()"
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        st.ensure_adam_state()
+        step = torch.tensor([st.step], dtype=torch.int64, device=st.flat_p.device)
+        for t in (st.flat_p, st.adam_m, st.adam_v, step):
+            dist.broadcast(t, src=0, group=group)
+        st.step = int(step.item())
+    st.touch()            # every plan's packed operands are rebuilt from the broadcast weights
     plan = eng.last_plan
     sizes = {st.off(p): p.numel() for p in st.params}
     module.reducer = GradAllReducer(st.flat_g, st.n, plan.ready_marks if plan is not None else None, sizes, group, always)
-    if plan is not None:
-        plan.packer.dirty = True
     return module.reducer

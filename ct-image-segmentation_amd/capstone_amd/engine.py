@@ -159,6 +159,10 @@ class ParamStore:
         self.flat_g = torch.zeros(self.n_pad, dtype=torch.float32, device=device)
         self.adam_m = self.adam_v = None
         self.step = 0
+        # bumped by every write to flat_p that bypasses the Parameters' own version counters (ctseg_adam_step writes through raw
+        # pointers; broadcasts and re-attach copies write the flat buffer): EVERY plan's Packer compares it, so a plan of another
+        # shape (validation, sliding window, a short last batch) never runs on packed weights from before the update
+        self.generation = 0
         with torch.no_grad():
             for p in self.params:
                 o = self.offsets[id(p)]
@@ -189,16 +193,24 @@ class ParamStore:
         return self.flat_g[o:o + p.numel()].view(p.shape)
 
     def version(self):
-        return sum(p._version for p in self.params)
+        return (self.generation, sum(p._version for p in self.params))
 
-    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
-        """torch.optim.Adam semantics (capstone/volumetric/base_trainer.py:113-114), one launch."""
+    def touch(self):
+        """flat_p was rewritten behind the Parameters' backs: every plan's packed operands are stale"""
+        self.generation += 1
+
+    def ensure_adam_state(self):
         if self.adam_m is None:
             self.adam_m = torch.zeros_like(self.flat_g)
             self.adam_v = torch.zeros_like(self.flat_g)
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        """torch.optim.Adam semantics (capstone/volumetric/base_trainer.py:113-114), one launch."""
+        self.ensure_adam_state()
         self.step += 1
         nat.call("ctseg_adam_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.adam_m.data_ptr(),
                  self.adam_v.data_ptr(), self.n, lr, betas[0], betas[1], eps, self.step, grad_scale)
+        self.touch()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -305,6 +305,7 @@ class Plan:
         self._defer = None
         self._keep = []
         self.ready_marks = []          # (program index in bwd, flat offset end) for gradient all-reduce overlap
+        self.fwd_gen = 0               # forwards run on this plan's (single) set of activation buffers
         self.shape = (N, X, Y, Z)
         cin = net.in_channels
         self.root = _Level(self, net.model, "model", cin, True)
@@ -400,6 +401,7 @@ class Plan:
             torch.cuda.current_stream(self.device).wait_event(ev)
             self._repack_ev = None
         self.packer.refresh()
+        self.fwd_gen += 1
         self.run(self.fwd, nat.stream_ptr())
         return self.logits
 
@@ -528,6 +530,7 @@ class Engine:
                     o = self.store.off(p)
                     self.store.flat_p[o:o + p.numel()].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
             self.store.attach()
+            self.store.touch()       # `p.data = ...` keeps the Parameters' version counters: the packed operands are stale anyway
         return self.store
 
     def plan_for(self, x, inference=False):
@@ -594,15 +597,20 @@ class Engine:
 class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, engine, plan, *params):
+        """Returns a VIEW of the plan's logits buffer (the fused loss pass reads it in place, channels-last): a later forward
+        on the same shape overwrites it, like the activations this node's backward needs — clone it to keep a prediction
+        across steps.  ``backward`` refuses to run on overwritten activations (generation check) instead of returning
+        gradients of the wrong batch."""
         plan.forward(x)
-        ctx.engine, ctx.plan = engine, plan
-        out = engine.logits_view(plan)
-        ctx.mark_non_differentiable()
-        return out
+        ctx.engine, ctx.plan, ctx.gen = engine, plan, plan.fwd_gen
+        return engine.logits_view(plan)
 
     @staticmethod
     def backward(ctx, g):
         engine, plan = ctx.engine, ctx.plan
+        if plan.fwd_gen != ctx.gen:
+            raise RuntimeError("the activations of this forward were overwritten by a later forward on the same input shape "
+                               "(one set of activation buffers per shape): call backward() before the next training forward")
         fused = getattr(plan, "dlogits_is_current", False)
         if not fused:
             C = engine.net.out_channels

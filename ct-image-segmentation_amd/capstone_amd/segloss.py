@@ -127,6 +127,7 @@ class SegLossEngine:
         out = torch.empty(1 + self.C, dtype=torch.float32, device=self.device)
         nat.call("ctseg_loss_dice_summary", (self.red_w if weighted else self.red).data_ptr(), self.B, self.R, self.cnt.data_ptr(),
                  self.C, out.data_ptr())
+        self.last_summary = out
         return out[0], out[1], out[2:]
 
     def predictions(self, logits_ptr, ld):

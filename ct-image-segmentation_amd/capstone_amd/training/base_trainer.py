@@ -35,6 +35,9 @@ class BaseUNet2D(_Base):
         else:
             self.save_hyperparameters(*names, frame_locals=dict(locals()))
         self._precision = _precision(kwargs)
+        # reference :53 builds this 3->1 convolution whatever ``downsample`` says, so its two tensors are in every reference
+        # checkpoint: kept as a parameter container for state_dict interchange
+        self.conv1x1 = torch.nn.Conv2d(in_channels=3, out_channels=1, kernel_size=1, stride=1)
         self.unet = self._construct_model()
         self.loss_func = MultipleLossWrapper(losses=loss_fx, exclude_missing=exclude_missing)
         self.dice_score = DiceMetricWrapper()
@@ -96,16 +99,16 @@ class BaseUNet2D(_Base):
     def add_model_specific_args(parent_parser):
         """Same flags and defaults as reference :150-210."""
         parser = ArgumentParser(parents=[parent_parser], add_help=False)
-        parser.add_argument("--batch_size", type=int, default=128, help="Batch size")
+        parser.add_argument("--batch_size", type=int, default=128, help="Slices per optimizer step")
         parser.add_argument("--transform_degree", type=int, default=0,
-                            help="The degree of transforms/data augmentation to be applied")
+                            help="Augmentation preset index (0 = none)")
         parser.add_argument("--filters", nargs=5, type=int, default=[64, 128, 256, 512, 1024],
-                            help="A sqeuence of number of filters for the downsampling path in UNet")
-        parser.add_argument("--use_res_units", action="store_true", default=False, help="For using residual units in UNet")
+                            help="Channel widths of the five encoder levels")
+        parser.add_argument("--use_res_units", action="store_true", default=False, help="Build the U-Net from residual units")
         parser.add_argument("--downsample", action="store_true", default=False,
-                            help="For using a 1x1 convolution to downsample the input before UNet")
-        parser.add_argument("--lr", type=float, default=1e-3, help="Learning rate")
-        parser.add_argument("--loss_fx", nargs="+", type=str, default=["Focal", "Dice"], help="Loss function")
+                            help="Reduce a 3-channel input to 1 channel with a 1x1 convolution before the U-Net")
+        parser.add_argument("--lr", type=float, default=1e-3, help="Adam step size")
+        parser.add_argument("--loss_fx", nargs="+", type=str, default=["Focal", "Dice"], help="One or more loss names, summed")
         parser.add_argument("--exclude_missing", action="store_true", default=False,
-                            help="Exclude missing annotations from loss computation as described in AnatomyNet")
+                            help="Weight per-class loss terms by annotation availability (AnatomyNet)")
         return parser

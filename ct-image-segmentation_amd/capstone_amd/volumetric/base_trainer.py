@@ -37,13 +37,52 @@ except Exception:  # noqa: BLE001
             super().__init__()
             self.hparams = _HParams()
             self.logged = {}
+            self._epoch = {}
 
         def save_hyperparameters(self, *names, frame_locals=None):
             for n in names:
                 self.hparams[n] = frame_locals.get(n, frame_locals.get("kwargs", {}).get(n))
 
-        def log(self, name, value, **kw):
-            self.logged[name] = value.detach() if torch.is_tensor(value) else value
+        def log(self, name, value, on_step=False, on_epoch=True, **kw):
+            """``logged[name]`` = the value of the last step; with ``on_epoch=True`` (what the reference passes everywhere,
+            volumetric/base_trainer.py:106-109,125-131) the value also enters a running sum whose mean over the steps of the
+            epoch is what Lightning 1.0 reports (``epoch_means``)."""
+            v = value.detach() if torch.is_tensor(value) else value
+            self.logged[name] = v
+            if on_epoch:
+                acc = self._epoch.get(name)
+                if acc is None:
+                    self._epoch[name] = [v.clone() if torch.is_tensor(v) else v, 1]
+                else:
+                    acc[0] = acc[0] + v
+                    acc[1] += 1
+
+        def log_packed(self, packed, layout):
+            """several logged values that are slices of ONE small device tensor (the native step's loss / Dice summary):
+            one accumulate for all of them instead of one tiny launch per name.  layout: [(name, index or slice)]"""
+            packed = packed.detach()
+            for name, sl in layout:
+                self.logged[name] = packed[sl]
+            key = ("packed",) + tuple(n for n, _ in layout)
+            acc = self._epoch.get(key)
+            if acc is None:
+                self._epoch[key] = [packed.clone(), 1, layout]
+            else:
+                acc[0] += packed
+                acc[1] += 1
+
+        def epoch_means(self, reset=True):
+            """{name: mean over the steps logged since the last reset} — Lightning's ``on_epoch=True`` reduction"""
+            out = {}
+            for k, acc in self._epoch.items():
+                if isinstance(k, tuple):
+                    mean = acc[0] / acc[1]
+                    out.update({name: mean[sl] for name, sl in acc[2]})
+                else:
+                    out[k] = acc[0] / acc[1]
+            if reset:
+                self._epoch = {}
+            return out
 
         @property
         def device(self):
@@ -168,7 +207,7 @@ class BaseUNet3D(_Base):
         def bookkeeping():     # scalar-sized work: queued behind the backward pass, beside the side stream's tail
             if ce_only:        # one launch for loss + Dice
                 loss, dm, dpc = le.ce_summary(weighted=names[0] != "CrossEntropy")
-                book["vals"], book["total"], book["dice"] = {names[0]: loss}, loss, (dm, dpc)
+                book["vals"], book["total"], book["dice"], book["packed"] = {names[0]: loss}, loss, (dm, dpc), le.last_summary
                 return
             book["vals"] = vals
             book["total"] = torch.stack([vals[n] for n in names]).sum()
@@ -184,26 +223,92 @@ class BaseUNet3D(_Base):
         plan.repack_after_update()
         vals, total = book["vals"], book["total"]
         dice_mean, dice_per_class = book["dice"]
-        for n in names:
-            self.log(f"{n} Loss (train)", vals[n])
-        self.log("Mean Dice Score (train)", dice_mean)
-        self.log("Dice per class (train)", dice_per_class)
+        if "packed" in book and pl is None:
+            self.log_packed(book["packed"], [(f"{names[0]} Loss (train)", 0), ("Mean Dice Score (train)", 1),
+                                             ("Dice per class (train)", slice(2, None))])
+        else:
+            for n in names:
+                self.log(f"{n} Loss (train)", vals[n], on_step=False, on_epoch=True)
+            self.log("Mean Dice Score (train)", dice_mean, on_step=False, on_epoch=True)
+            if pl is None:
+                self.log("Dice per class (train)", dice_per_class, on_step=False, on_epoch=True)
+            else:   # Lightning logs scalars: one entry per structure, as the reference's _log_dice_scores does (:125-129)
+                for structure, score in zip(STRUCTURES, dice_per_class):
+                    self.log(f"{structure} Dice (train)", score, on_step=False, on_epoch=True)
         return total
+
+    # ---- optimizer state of the native step, in torch.optim.Adam's own state_dict layout ------------------------------
+    # The reference checkpoints through Lightning's ModelCheckpoint (volumetric/base_trainer.py:224-225), which stores
+    # ``optimizer.state_dict()`` next to the module's ``state_dict``.  fit_step keeps Adam's moments in the flat store, outside any
+    # torch optimizer, so the module exports / imports them in exactly that layout: a checkpoint written after native steps
+    # resumes under ``configure_optimizers()``'s torch Adam and vice versa, and ``state_dict()`` keeps the reference's keys only.
+    def optimizer_state_dict(self, betas=(0.9, 0.999), eps=1e-8):
+        st = self.unet.engine().store
+        params = list(self.parameters())
+        state = {}
+        if st is not None and st.step > 0:
+            for i, p in enumerate(params):
+                o, n = st.off(p), p.numel()
+                state[i] = {"step": torch.tensor(float(st.step)), "exp_avg": st.adam_m[o:o + n].view(p.shape).clone(),
+                            "exp_avg_sq": st.adam_v[o:o + n].view(p.shape).clone()}
+        group = {"lr": self.hparams.lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False,
+                 "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        eng = self.unet.engine()
+        st = eng.ensure(self.device)
+        params = list(self.parameters())
+        state = sd["state"]
+        if not state:
+            st.adam_m = st.adam_v = None
+            st.step = 0
+            return
+        steps = {int(float(v["step"])) for v in state.values()}
+        if len(state) != len(params) or len(steps) != 1:
+            raise ValueError("optimizer state does not cover every parameter with one common step count")
+        st.ensure_adam_state()
+        with torch.no_grad():
+            for i, p in enumerate(params):
+                o, n = st.off(p), p.numel()
+                e = state[i] if i in state else state[str(i)]
+                st.adam_m[o:o + n].copy_(e["exp_avg"].reshape(-1))
+                st.adam_v[o:o + n].copy_(e["exp_avg_sq"].reshape(-1))
+        st.step = steps.pop()
+
+    def on_save_checkpoint(self, checkpoint):
+        """Lightning hook: the native step's Adam state rides in the checkpoint under its own key"""
+        checkpoint["ctseg_native_adam"] = self.optimizer_state_dict()
+
+    def on_load_checkpoint(self, checkpoint):
+        if checkpoint.get("ctseg_native_adam", {}).get("state"):
+            self.load_optimizer_state_dict(checkpoint["ctseg_native_adam"])
+
+    def checkpoint(self):
+        """what Lightning's ModelCheckpoint would write for this module (weights + optimizer state + hparams)"""
+        ck = {"state_dict": self.state_dict(), "hyper_parameters": dict(self.hparams),
+              "optimizer_states": [self.optimizer_state_dict()]}
+        return ck
+
+    def load_checkpoint(self, ck):
+        self.load_state_dict(ck["state_dict"])
+        if ck.get("optimizer_states"):
+            self.load_optimizer_state_dict(ck["optimizer_states"][0])
 
     @staticmethod
     def add_model_specific_args(parent_parser):
         """Same flags and defaults as reference :134-182."""
         parser = ArgumentParser(parents=[parent_parser], add_help=False)
-        parser.add_argument("--batch_size", type=int, default=1, help="Batch size")
+        parser.add_argument("--batch_size", type=int, default=1, help="Volumes per optimizer step")
         parser.add_argument("--transform_degree", type=int, default=0,
-                            help="The degree of transforms/data augmentation to be applied")
+                            help="Augmentation preset index (0 = none)")
         parser.add_argument("--filters", nargs=5, type=int, default=[64, 128, 256, 512, 1024],
-                            help="A sqeuence of number of filters for the downsampling path in UNet")
-        parser.add_argument("--use_res_units", action="store_true", default=False, help="For using residual units in UNet")
+                            help="Channel widths of the five encoder levels")
+        parser.add_argument("--use_res_units", action="store_true", default=False, help="Build the U-Net from residual units")
         parser.add_argument("--downsample", action="store_true", default=False,
-                            help="For using a 1x1 convolution to downsample the input before UNet")
-        parser.add_argument("--lr", type=float, default=1e-3, help="Learning rate")
-        parser.add_argument("--loss_fx", nargs="+", type=str, default="CrossEntropy", help="Loss function")
+                            help="Reduce a 3-channel input to 1 channel with a 1x1 convolution before the U-Net")
+        parser.add_argument("--lr", type=float, default=1e-3, help="Adam step size")
+        parser.add_argument("--loss_fx", nargs="+", type=str, default="CrossEntropy", help="One or more loss names, summed")
         parser.add_argument("--exclude_missing", action="store_true", default=False,
-                            help="Exclude missing annotations from loss computation as described in AnatomyNet")
+                            help="Weight per-class loss terms by annotation availability (AnatomyNet)")
         return parser

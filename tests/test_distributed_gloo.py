@@ -75,3 +75,112 @@ def test_world1_is_a_no_op():
     g = torch.ones(8)
     red = cdist.GradAllReducer(g, 8)
     assert red.hooks() == {} and red.finish() == 1.0 and torch.equal(g, torch.ones(8))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the data-parallel STEP, checked as a step: two ranks run the product's real fit_step (host logic + C-ABI emulator on CPU
+# memory, gloo all-reduce fired from the backward hooks) on their own half of a batch; the oracle steps once per iteration on
+# the concatenated batch.  Lightning DDP semantics (capstone/volumetric/base_trainer.py:196): identical replicas, gradient mean.
+# ------------------------------------------------------------------------------------------------------------------------
+FILTERS = (4, 8, 16)
+STEPS = 3
+
+
+def _ddp_batches():
+    g = torch.Generator().manual_seed(77)
+    out = []
+    for r in range(2):
+        x = torch.randn(1, 1, 8, 8, 8, generator=g)
+        m = (torch.rand(1, 9, 8, 8, 8, generator=g) < 0.12).to(torch.uint8)
+        out.append((x, m, torch.ones(1, 9)))
+    return out
+
+
+def _ddp_worker(rank, world, port, q, warm_local_steps):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from abi_emulator import Emulator, patch_native
+    from capstone_amd import _native as nat, plan as plan_mod
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    e = Emulator()
+    patch_native(nat, e)
+    plan_mod.Plan.run = staticmethod(lambda prog, stream, lo=0, hi=None: e.run(prog[lo:hi]))
+    cdist.init_from_env("gloo")
+    torch.manual_seed(100 + rank)                     # DIFFERENT initial weights per rank: attach() must make them rank 0's
+    m = BaseUNet3D(filters=list(FILTERS), loss_fx=["CrossEntropy"], lr=0.01)
+    batch = _ddp_batches()[rank]
+    for _ in range(warm_local_steps):                 # rank-local optimizer steps before attach: moments and step count diverge
+        m.fit_step(batch)
+    m.unet.engine().ensure("cpu")
+    red = cdist.attach(m)
+    st = m.unet.engine().store
+    p_attach = st.flat_p.clone().numpy()
+    losses = []
+    for _ in range(STEPS):
+        losses.append(float(m.fit_step(batch)))
+        assert red.points_for(m.unet.engine().last_plan), "a chunk must go out mid-backward"
+    q.put((rank, p_attach, st.flat_p.clone().numpy(), st.adam_m.clone().numpy(), st.adam_v.clone().numpy(), st.step, losses,
+           {k: v.clone().numpy() for k, v in m.state_dict().items()}))
+    dist.destroy_process_group()
+
+
+def _run_ddp(warm_local_steps):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, warm_local_steps)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_rank_fit_step_equals_one_process_on_the_concatenated_batch():
+    from oracle.trainer import OracleUNet3D
+    r0, r1 = _run_ddp(0)
+    # (i) replicas: bit-identical weights, moments and step count on both ranks after K steps
+    for i in (1, 2, 3, 4):
+        np.testing.assert_array_equal(r0[i], r1[i])
+    assert r0[5] == r1[5] == STEPS
+    # (ii) == one process stepping on the concatenated batch (CE is a mean over all voxels and both ranks hold the same number
+    # of voxels, so the mean over ranks of the rank gradients is the gradient of the concatenated loss)
+    torch.manual_seed(100)                             # rank 0's initial weights
+    om = OracleUNet3D(filters=FILTERS, loss_fx=("CrossEntropy",), lr=0.01)
+    sd0 = {k: v.clone() for k, v in om.state_dict().items()}
+    opt = om.configure_optimizers()
+    b = _ddp_batches()
+    cat = tuple(torch.cat([b[0][i], b[1][i]]) for i in range(3))
+    solid = {k: torch.ones_like(p, dtype=torch.bool) for k, p in om.named_parameters()}
+    olosses = []
+    for _ in range(STEPS):
+        olosses.append(float(om.fit_step(cat, opt)))
+        for k, p in om.named_parameters():
+            gmax = float(p.grad.abs().max())
+            solid[k] &= p.grad.abs() > 1e-3 * max(gmax, 1e-9)
+    # loss of the concatenated batch = mean of the two rank losses
+    np.testing.assert_allclose((np.array(r0[6]) + np.array(r1[6])) / 2, olosses, rtol=2e-4)
+    moved = 0
+    for k, p in om.named_parameters():
+        got, ref = r0[7][k], p.detach().numpy()
+        ok = solid[k].numpy()
+        if k.endswith(".bias") and "residual" not in k:   # bias before an InstanceNorm: analytically zero gradient, noise only
+            ok = ok & False
+        # where the gradient is above the noise floor at every step Adam moved the weight the same way on both sides
+        np.testing.assert_allclose(got[ok], ref[ok], rtol=0, atol=4e-4, err_msg=k)
+        moved += int((np.abs(ref - sd0[k].numpy())[ok] > 5e-3).sum())
+        # everywhere else the difference is bounded by K steps of size lr
+        np.testing.assert_allclose(got, ref, rtol=0, atol=STEPS * 0.01 * 2.05, err_msg=k)
+    assert moved > 100, "the comparison must cover weights that actually moved"
+
+
+def test_attach_after_rank_local_steps_replicates_adam_state_too():
+    """attach() after each rank has already taken optimizer steps of its own (the round-1 bench did one): weights, BOTH Adam
+    moment buffers and the step count must become rank 0's, or the replicas apply different updates to the same mean gradient."""
+    r0, r1 = _run_ddp(2)
+    np.testing.assert_array_equal(r0[1], r1[1])        # weights right after attach
+    for i in (2, 3, 4):
+        np.testing.assert_array_equal(r0[i], r1[i])    # weights and both moments after K more steps
+    assert r0[5] == r1[5] == 2 + STEPS

@@ -288,6 +288,23 @@ def _load_tiny(golden, tag, precision):
     return g, m, batch
 
 
+def _assert_adam_moved_like_fixture(w_got, w0, w1_ref, g_ref, key, lr=1e-3):
+    """Adam's first step moves a weight by lr * g / (|g| + eps) ~ -lr * sign(g).  For every element whose fixture gradient is
+    above the noise floor: the step taken has the fixture's SIGN and its size (|w1 - w0| ~ lr), i.e. a step that never ran, ran
+    twice, or ran on the wrong gradient fails.  (Biases feeding an InstanceNorm hold rounding noise only: excluded.)  Returns the
+    number of elements checked."""
+    if key.endswith(".bias") and "residual" not in key:
+        return 0
+    solid = np.abs(g_ref) > 1e-3 * max(float(np.abs(g_ref).max()), 1e-6)
+    if not solid.any():
+        return 0
+    step_got, step_ref = (w_got - w0)[solid], (w1_ref - w0)[solid]
+    assert np.all(np.abs(step_ref) > 0.5 * lr), key                # the fixture itself moved these by ~lr
+    np.testing.assert_array_equal(np.sign(step_got), np.sign(step_ref), err_msg=key + " (direction of the Adam step)")
+    np.testing.assert_allclose(np.abs(step_got), np.abs(step_ref), rtol=0, atol=0.05 * lr, err_msg=key + " (size of the Adam step)")
+    return int(solid.sum())
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_tiny_step_fp32_matches_oracle_fixture(golden, tag):
     g, m, batch = _load_tiny(golden, tag, "fp32")
@@ -299,12 +316,14 @@ def test_tiny_step_fp32_matches_oracle_fixture(golden, tag):
     np.testing.assert_allclose(loss.item(), g[f"{tag}_loss"], rtol=1e-5)
     np.testing.assert_allclose(m.logged["Mean Dice Score (train)"].item(), g[f"{tag}_dice_mean"], atol=2e-3)
     np.testing.assert_allclose(m.logged["Dice per class (train)"].cpu().numpy(), g[f"{tag}_dice_per_class"], atol=2e-3)
+    checked = 0
     for k, p in m.named_parameters():
         ref = g[f"{tag}_g:{k}"]
         scale = max(1.0, float(np.abs(ref).max()))
         atol = (5e-3 if (k.endswith(".bias") and "residual" not in k) else 5e-5) * scale
         np.testing.assert_allclose(eng.store.grad_view(p).cpu().numpy(), ref, rtol=3e-3, atol=atol, err_msg=k)
-        np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"{tag}_w1:{k}"], rtol=0, atol=2.1e-3, err_msg=k)
+        checked += _assert_adam_moved_like_fixture(p.detach().cpu().numpy(), g[f"{tag}_w:{k}"], g[f"{tag}_w1:{k}"], ref, k)
+    assert checked > 0.5 * sum(p.numel() for p in m.parameters()), "the post-Adam check must cover most of the weights"
 
 
 def test_masks_bit_exact_where_margin(golden):
@@ -335,8 +354,21 @@ def test_autograd_drop_in_path_equals_native_step(golden):
     opt.step()
     loss2 = m2.fit_step(batch)
     np.testing.assert_allclose(loss.item(), loss2.item(), rtol=1e-6)
+    checked = 0
     for (k, p), q in zip(m1.named_parameters(), m2.parameters()):
-        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=0, atol=2.1e-3, err_msg=k)
+        # both paths replay the same recorded conv / norm programs; only the loss gradient is produced by different passes (stats +
+        # gradient vs the fused CE pass), so gradients agree to rounding and, wherever the gradient is not itself rounding noise,
+        # torch's Adam and ctseg_adam_step land within a small fraction of one step (lr = 1e-3) of each other
+        w0, wa, wn = g[f"b_w:{k}"], p.detach().cpu().numpy(), q.detach().cpu().numpy()
+        gref = g[f"b_g:{k}"]
+        real = np.abs(gref) > 1e-4 * max(float(np.abs(gref).max()), 1e-6)
+        if k.endswith(".bias") and "residual" not in k:
+            real &= False
+        np.testing.assert_allclose(wa[real], wn[real], rtol=0, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(wa, wn, rtol=0, atol=2.1e-3, err_msg=k)
+        checked += _assert_adam_moved_like_fixture(wn, w0, g[f"b_w1:{k}"], g[f"b_g:{k}"], k)
+        assert np.abs(wa - w0).max() > 0.5e-3, k                    # and a step was taken at all
+    assert checked > 0.5 * sum(p.numel() for p in m1.parameters())
     # second forward after the torch optimizer changed the weights in place: packed operands must refresh
     l1b = m1.training_step(batch, 1).item()
     l2b = m2.fit_step(batch).item()

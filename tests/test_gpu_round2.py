@@ -1,0 +1,289 @@
+"""GPU parity tests added in round 2 (run with -m gpu on a MI355X), all through the C ABI:
+  * the ``exclude_missing`` branch of the loss zoo (capstone/models/losses.py:196-221) on 5-D logits: values and d/dlogits,
+  * full-size (BASELINE.json configs[2] volume) fp32 step against the CPU oracle,
+  * K-step training trajectories (configs[1] shape) in fp32 and bf16 against the oracle's curve,
+  * an optimizer update on one plan reaching every other cached plan,
+  * the checkpoint layout of the native step's Adam state.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from capstone_amd import segloss  # noqa: E402
+
+DEV = "cuda:0"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _dump(name, obj):
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, name), "w") as f:
+            json.dump(obj, f, indent=1)
+    except OSError:
+        pass
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# (a) exclude_missing
+# ----------------------------------------------------------------------------------------------------------------------
+def test_mask_weight_tables_match_the_reference_run_apply_missing_mask(golden):
+    """the product folds apply_missing_mask (models/losses.py:206-221) into per-(sample, class) weights of the loss table
+    (SegLossEngine._mask_weights).  Against the reference's OWN outputs (ref_leaf.npz mm_*): both indicator patterns for Dice
+    (b zeroes a class everywhere -> the isinf -> uniform-weights branch, :216-217) and the Focal background column (:207-212)."""
+    from capstone_amd.models.losses import apply_missing_mask
+    leaf = golden("ref_leaf.npz")
+    B = leaf["mm_table"].shape[0]
+    le = segloss.SegLossEngine(torch.device(DEV), B, 64, 10)
+    t9, t10 = torch.from_numpy(leaf["mm_table"]).to(DEV), torch.from_numpy(leaf["mm_table10"]).to(DEV)
+    assert (leaf["mm_ind_b"].sum(0) == 0).any(), "fixture b must hold a class nobody annotated (the isinf branch)"
+    for name, table, ind_key, want in (("Dice", t9, "mm_ind_a", "mm_dice_a"), ("Dice", t9, "mm_ind_b", "mm_dice_b"),
+                                       ("Focal", t10, "mm_ind_a", "mm_focal_a")):
+        ind = torch.from_numpy(leaf[ind_key]).to(DEV)
+        wt = le._mask_weights(name, ind, True, table.shape[1])
+        np.testing.assert_allclose(float((table * wt).sum()), leaf[want], rtol=2e-6, err_msg=f"{name}/{ind_key} (table weights)")
+        np.testing.assert_allclose(float(apply_missing_mask(name, table, ind)), leaf[want], rtol=2e-6, err_msg=f"{name}/{ind_key}")
+
+
+@pytest.mark.parametrize("pattern", ["class_missing_everywhere", "class_missing_in_one_sample", "all_annotated"])
+def test_exclude_missing_losses_values_and_dlogits_on_5d_logits(pattern):
+    """MultipleLossWrapper(["Dice","Focal","GeneralizedDice"], exclude_missing=True) on (B,10,H,W,D) logits: the reduction
+    "none" tables, the indicator weighting and the per-sample gradient coefficients, against oracle.losses.MultipleLoss
+    (whose missing_mask is pinned bit-exactly to the reference's, tests/test_oracle_golden.py)."""
+    from capstone_amd.models.losses import MultipleLossWrapper
+    from oracle import losses as OL
+    g = torch.Generator().manual_seed(41)
+    B, H, W, D = 3, 8, 12, 4
+    logits = torch.randn(B, 10, H, W, D, generator=g) * 2.0
+    target = torch.randint(0, 10, (B, H, W, D), generator=g)
+    target[1][target[1] == 6] = 0                      # class 6 absent from sample 1: GDL's inf -> max weight path
+    ind = torch.ones(B, 9)
+    if pattern == "class_missing_everywhere":
+        ind[:, 2] = 0                                  # 1 / 0 -> inf -> uniform weights (models/losses.py:216-217)
+        ind[0, 5] = 0
+    elif pattern == "class_missing_in_one_sample":
+        ind[2, 4] = 0
+        ind[0, 7] = 0                                  # two samples incomplete: Focal's background column is 0 for them
+    names = ["Dice", "Focal", "GeneralizedDice"]
+    xr = logits.clone().requires_grad_(True)
+    rv = OL.MultipleLoss(names, exclude_missing=True)(xr, target, ind)
+    torch.stack(list(rv.values())).sum().backward()
+    x = logits.to(DEV).requires_grad_(True)
+    v = MultipleLossWrapper(names, exclude_missing=True)(input=x, target=target.to(DEV), mask_indicator=ind.to(DEV))
+    for n in names:
+        np.testing.assert_allclose(v[n].item(), rv[n].item(), rtol=2e-5, atol=1e-7, err_msg=n)
+    torch.stack(list(v.values())).sum().backward()
+    got, ref = x.grad.cpu().numpy(), xr.grad.numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-6 * float(np.abs(ref).max()) + 1e-9)
+    assert float(np.abs(ref).max()) > 1e-6
+    # one loss at a time, with a non-unit upstream gradient: the coefficient tables are per loss
+    for n, scale in zip(names, (0.5, 2.0, 3.0)):
+        xr1 = logits.clone().requires_grad_(True)
+        (OL.MultipleLoss([n], exclude_missing=True)(xr1, target, ind)[n] * scale).backward()
+        x1 = logits.to(DEV).requires_grad_(True)
+        (MultipleLossWrapper([n], exclude_missing=True)(input=x1, target=target.to(DEV), mask_indicator=ind.to(DEV))[n] * scale).backward()
+        r1 = xr1.grad.numpy()
+        np.testing.assert_allclose(x1.grad.cpu().numpy(), r1, rtol=2e-3, atol=2e-6 * float(np.abs(r1).max()) + 1e-9, err_msg=n)
+
+
+def test_exclude_missing_training_step_through_the_network():
+    """BaseUNet3D(loss_fx=[Dice, Focal], exclude_missing=True): fit_step (native) and training_step (autograd surface) against the
+    oracle step with the same indicator — loss values, gradient direction, Dice metric."""
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    import oracle.trainer as OT
+    torch.manual_seed(9)
+    filters = (8, 16, 32)
+    om = OT.OracleUNet3D(filters=filters, loss_fx=("Dice", "Focal"), exclude_missing=True)
+    g = torch.Generator().manual_seed(10)
+    images = torch.randn(2, 1, 16, 16, 8, generator=g)
+    masks = torch.zeros(2, 9, 16, 16, 8, dtype=torch.uint8)
+    for c in range(9):
+        masks[:, c, c:c + 6, 2 + c:9 + c, 1:7] = 1
+    ind = torch.ones(2, 9)
+    ind[:, 3] = 0
+    ind[1, 8] = 0
+    oloss = om.training_step((images, masks, ind))
+    oloss.backward()
+    batch = (images.to(DEV), masks.to(DEV), ind.to(DEV))
+    for mode in ("native", "autograd"):
+        m = BaseUNet3D(filters=list(filters), loss_fx=["Dice", "Focal"], exclude_missing=True)
+        m.load_state_dict(om.state_dict())
+        m.to(DEV)
+        if mode == "native":
+            loss = m.fit_step(batch)
+            grads = {k: m.unet.engine().store.grad_view(p).cpu() for k, p in m.named_parameters()}
+        else:
+            loss = m.training_step(batch)
+            loss.backward()
+            grads = {k: p.grad.cpu() for k, p in m.named_parameters()}
+        np.testing.assert_allclose(loss.item(), oloss.item(), rtol=1e-4, err_msg=mode)
+        for n in ("Dice", "Focal"):
+            np.testing.assert_allclose(m.logged[f"{n} Loss (train)"].item(), om.logged[f"{n} Loss (train)"].item(), rtol=1e-4)
+        assert abs(m.logged["Mean Dice Score (train)"].item() - om.logged["Mean Dice Score (train)"].item()) <= 0.002
+        for k, p in om.named_parameters():
+            a, b = grads[k].flatten().double(), p.grad.flatten().double()
+            if b.norm() > 1e-5:
+                assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.9999, (mode, k)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# (c) full-size fp32 step vs the oracle
+# ----------------------------------------------------------------------------------------------------------------------
+def test_full_size_fp32_step_vs_oracle():
+    """ONE volume of BASELINE.json's metric shape, 1x1x512x512x48, fp32 storage (v_mfma_f32_16x16x4_f32), the real network
+    (32,64,128,256): forward + CrossEntropy + Dice metric + backward against the CPU oracle (~20 s of host time).
+    north_star's bar: logits within 1e-3, argmax masks equal wherever the top-2 margin exceeds the logit error, Dice +-0.002."""
+    from bench import synthetic_batch
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    from oracle.metrics import squash_predictions
+    import oracle.trainer as OT
+    torch.manual_seed(12342)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    om = OT.OracleUNet3D(filters=(32, 64, 128, 256), loss_fx=("CrossEntropy",))
+    m = BaseUNet3D(filters=[32, 64, 128, 256], loss_fx=["CrossEntropy"], precision="fp32")
+    m.load_state_dict(om.state_dict())
+    m.to(DEV)
+    batch = synthetic_batch(1, 512, 512, 48, "cpu", 12342)
+    _, _, _, ologits, oloss = om.shared_step(batch, True)
+    oloss.backward()
+    ologits = ologits.detach()
+    loss = m.fit_step(tuple(t.to(DEV) for t in batch))
+    eng = m.unet.engine()
+    logits = eng.logits_view().cpu()
+    err = float((logits - ologits).abs().max())
+    odice, dice = float(om.logged["Mean Dice Score (train)"]), float(m.logged["Mean Dice Score (train)"])
+    top2 = ologits.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 4 * max(err, 1e-6)
+    pred = m.unet.engine().last_plan._ctseg_loss.predictions(eng.last_plan.logits.ptr(), eng.last_plan.logits.ld).cpu().long()
+    opred = squash_predictions(ologits).reshape(1, -1)
+    flips = int((pred != opred).sum())
+    cos = []
+    for (k, p), q in zip(om.named_parameters(), m.parameters()):
+        a, b = eng.store.grad_view(q).cpu().flatten().double(), p.grad.flatten().double()
+        if b.norm() > 1e-4:
+            cos.append((float(torch.dot(a, b) / (a.norm() * b.norm())), k))
+    _dump("full_size_fp32_vs_oracle.json", {"logits_max_abs_err": err, "loss": loss.item(), "oracle_loss": oloss.item(),
+                                            "dice": dice, "oracle_dice": odice, "safe_fraction": float(safe.float().mean()),
+                                            "mask_flips_total": flips, "voxels": int(opred.numel()), "min_grad_cos": min(cos)})
+    assert err < 1e-3, err
+    assert abs(loss.item() - oloss.item()) < 1e-4 * abs(oloss.item())
+    assert abs(dice - odice) <= 0.002
+    assert float(safe.float().mean()) > 0.99
+    assert torch.equal(pred.reshape(-1)[safe.reshape(-1)], opred.reshape(-1)[safe.reshape(-1)])
+    assert flips <= 50, flips                      # near-ties below the logit error may flip; O(10) per volume expected
+    assert min(cos)[0] > 0.9999, min(cos)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# (d) K-step trajectories
+# ----------------------------------------------------------------------------------------------------------------------
+K_STEPS = 12
+
+
+def _oracle_curve(filters, batch, lr):
+    import oracle.trainer as OT
+    torch.manual_seed(12342)
+    om = OT.OracleUNet3D(filters=filters, loss_fx=("CrossEntropy",), lr=lr)
+    sd = {k: v.clone() for k, v in om.state_dict().items()}
+    opt = om.configure_optimizers()
+    losses, dices = [], []
+    for _ in range(K_STEPS):
+        losses.append(float(om.fit_step(batch, opt)))
+        dices.append(float(om.logged["Mean Dice Score (train)"]))
+    return sd, losses, dices
+
+
+@pytest.fixture(scope="module")
+def trajectory_oracle():
+    from bench import synthetic_batch
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    batch = synthetic_batch(1, 128, 128, 32, "cpu", 12342)
+    return batch, _oracle_curve((32, 64, 128, 256), batch, 1e-3)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_k_step_trajectory_tracks_the_oracle(trajectory_oracle, precision):
+    """BASELINE.json configs[1] (the real network on 1x1x128x128x32), K optimizer steps from the same weights on the same batch:
+    per-step CrossEntropy and mean Dice against the oracle's curve.  fp32 must stay within north_star's Dice +-0.002 (and 0.5 %
+    of the loss) at EVERY step; bf16 is measured against the same curve with the tolerance it meets written here."""
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    batch, (sd, olosses, odices) = trajectory_oracle
+    m = BaseUNet3D(filters=[32, 64, 128, 256], loss_fx=["CrossEntropy"], precision=precision, lr=1e-3)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    gb = tuple(t.to(DEV) for t in batch)
+    losses, dices = [], []
+    for _ in range(K_STEPS):
+        losses.append(float(m.fit_step(gb)))
+        dices.append(float(m.logged["Mean Dice Score (train)"]))
+    dl = [abs(a - b) / abs(b) for a, b in zip(losses, olosses)]
+    dd = [abs(a - b) for a, b in zip(dices, odices)]
+    _dump(f"trajectory_{precision}.json", {"steps": K_STEPS, "loss": losses, "oracle_loss": olosses, "dice": dices,
+                                           "oracle_dice": odices, "max_rel_loss_diff": max(dl), "max_abs_dice_diff": max(dd)})
+    assert olosses[-1] < 0.8 * olosses[0], "the curve must actually descend"
+    if precision == "fp32":
+        assert max(dd) <= 0.002, dd
+        assert max(dl) <= 5e-3, dl
+    else:
+        assert max(dd) <= 0.01, dd
+        assert max(dl) <= 3e-2, dl
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# stale packed weights / checkpoints
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_optimizer_update_reaches_every_cached_plan_on_gpu(precision):
+    """train on shape A, evaluate on shape B, train, evaluate: the native Adam kernel writes the flat parameter buffer through raw
+    pointers, every cached plan must rebuild its packed MFMA operands (store generation counter)."""
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    from oracle.trainer import OracleUNet3D
+    torch.manual_seed(2)
+    om = OracleUNet3D(filters=(8, 16, 32), loss_fx=("CrossEntropy",), lr=0.02)
+    m = BaseUNet3D(filters=[8, 16, 32], loss_fx=["CrossEntropy"], lr=0.02, precision=precision)
+    m.load_state_dict(om.state_dict())
+    m.to(DEV)
+    g = torch.Generator().manual_seed(4)
+    xa, xb = torch.randn(1, 1, 16, 16, 8, generator=g), torch.randn(2, 1, 8, 16, 4, generator=g)
+    masks = (torch.rand(1, 9, 16, 16, 8, generator=g) < 0.1).to(torch.uint8)
+    batch = (xa, masks, torch.ones(1, 9))
+    gb = tuple(t.to(DEV) for t in batch)
+    opt = om.configure_optimizers()
+    with torch.no_grad():
+        yb0 = m(xb.to(DEV)).clone().cpu()
+    for _ in range(2):
+        m.fit_step(gb)
+        om.fit_step(batch, opt)
+    with torch.no_grad():
+        yb1 = m(xb.to(DEV)).clone().cpu()
+    ref = om(xb).detach()
+    moved = float((ref - yb0).abs().max())
+    tol = 2e-3 if precision == "fp32" else 0.15
+    assert moved > 4 * tol, moved
+    assert float((yb1 - ref).abs().max()) < tol * max(1.0, float(ref.abs().max())), float((yb1 - ref).abs().max())
+
+
+def test_native_adam_state_checkpoint_round_trip_on_gpu():
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    torch.manual_seed(3)
+    g = torch.Generator().manual_seed(5)
+    batch = (torch.randn(1, 1, 16, 16, 8, generator=g).to(DEV), (torch.rand(1, 9, 16, 16, 8, generator=g) < 0.1).to(torch.uint8).to(DEV),
+             torch.ones(1, 9).to(DEV))
+    m1 = BaseUNet3D(filters=[8, 16, 32], loss_fx=["CrossEntropy"], precision="bf16").to(DEV)
+    for _ in range(2):
+        m1.fit_step(batch)
+    ck = m1.checkpoint()
+    ck = {"state_dict": {k: v.cpu() for k, v in ck["state_dict"].items()}, "hyper_parameters": ck["hyper_parameters"],
+          "optimizer_states": [{"state": {i: {k: v.cpu() for k, v in e.items()} for i, e in ck["optimizer_states"][0]["state"].items()},
+                                "param_groups": ck["optimizer_states"][0]["param_groups"]}]}
+    m2 = BaseUNet3D(filters=[8, 16, 32], loss_fx=["CrossEntropy"], precision="bf16").to(DEV)
+    m2.load_checkpoint(ck)
+    l1, l2 = float(m1.fit_step(batch)), float(m2.fit_step(batch))
+    assert l1 == l2
+    torch.cuda.synchronize()
+    assert torch.equal(m1.unet.engine().store.flat_p, m2.unet.engine().store.flat_p)

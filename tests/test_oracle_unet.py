@@ -29,6 +29,18 @@ def test_five_filter_variant_and_2d():
     assert y.shape == (1, 10, 32, 32)
 
 
+def test_parameter_counts_the_reference_report_publishes():
+    """The only reference-held numbers that touch the (otherwise unpinned) MONAI topology: reports/Report.pdf p.8 Table 1 —
+    Model L (2-D U-Net, filters 64..1024, 2 residual units) has 26 M parameters, Model M (1 residual unit per the Report;
+    the 2-D CLI's use_res_units switch gives 2 or 0) 13.5 M.  Built exactly as capstone/training/base_trainer.py:61-79 builds
+    them: UNet(dimensions=2, in_channels=1, out_channels=10, channels=filters, strides=[2,2,2,2], num_res_units=...)."""
+    filters = (64, 128, 256, 512, 1024)
+    count = lambda nres: sum(p.numel() for p in UNet(2, 1, 10, filters, (2, 2, 2, 2), num_res_units=nres).parameters())
+    n_l, n_m = count(2), count(1)
+    assert n_l == 25_980_905 and round(n_l / 1e6) == 26            # "26 M"
+    assert n_m == 13_408_292 and abs(n_m / 1e6 - 13.5) < 0.1       # "13.5 M"
+
+
 def test_tiny_step_fixture_reproduces(golden):
     g = golden("unet_tiny.npz")
     for tag in ("a", "b"):
