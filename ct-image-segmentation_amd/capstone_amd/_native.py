@@ -12,11 +12,17 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libctseg_hip.so")
 
-F32, BF16, I16, U8 = 0, 1, 2, 3
+F32, BF16, I16, U8, F16 = 0, 1, 2, 3, 4      # F16: IEEE half storage, forward (inference) passes only
 MAX_TAPS, MAX_CLASSES = 27, 8
-_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
-_EPC = {F32: 4, BF16: 8}
-_SZ = {F32: 4, BF16: 2}
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+_EPC = {F32: 4, BF16: 8, F16: 8}
+_SZ = {F32: 4, BF16: 2, F16: 2}
+DT_OF_PRECISION = {"fp32": F32, "bf16": BF16, "fp16": F16}
+
+
+def is16(dt):
+    """16-bit storage kinds: same layouts (8 elements per 16-byte chunk, 12-wide rows around 10 classes), same kernels"""
+    return dt in (BF16, F16)
 
 
 def torch_dtype(dt):

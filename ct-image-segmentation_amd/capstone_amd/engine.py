@@ -36,7 +36,7 @@ class Act:
 
     def __init__(self, t, C, c0=0, dt=None):
         self.t, self.C, self.c0 = t, C, c0
-        self.dt = dt if dt is not None else (F32 if t.dtype == torch.float32 else BF16)
+        self.dt = dt if dt is not None else {torch.float32: F32, torch.float16: nat.F16}.get(t.dtype, BF16)
 
     @property
     def dims(self):
@@ -87,7 +87,7 @@ NARROW_ROWS = [False]     # set while a Plan is being recorded (Engine.plan_for_
 
 def default_ld(C, dt):
     """channel stride of a fresh activation: 16-byte chunks; bf16 tensors of 9..12 channels 12 wide while NARROW_ROWS"""
-    if NARROW_ROWS[0] and dt == BF16 and rup(C, 4) == 12:
+    if NARROW_ROWS[0] and nat.is16(dt) and rup(C, 4) == 12:
         return 12
     return rup(C, nat.epc(dt))
 
@@ -297,12 +297,12 @@ class GemmLayer:
         d.Xr, d.Yr, d.Zr = rowgrid
         _, d.Xo, d.Yo, d.Zo = out.dims
         d.Cg, d.Cn = cg, Cn
-        narrow_out = plan.dt == BF16 and not out_f32 and out.ld == 12
+        narrow_out = nat.is16(plan.dt) and not out_f32 and out.ld == 12
         d.Cn_store = rup(Cn, 4 if (out_f32 or narrow_out) else nat.epc(plan.dt))
         assert out2 is not None or out.c0 + d.Cn_store <= out.ld, (self.name, out.c0, d.Cn_store, out.ld)
         d.g_ld, d.o_ld = gathered.ld, out.ld
         d.add_ld = add.ld if add is not None else 0
-        self._narrow = plan.dt == BF16 and (narrow_out or gathered.ld == 12 or
+        self._narrow = nat.is16(plan.dt) and (narrow_out or gathered.ld == 12 or
                                            (add is not None and add.t.dtype != torch.float32 and add.ld == 12))
         d.sin, d.sout = sin, sout
         d.out_f32 = 1 if out_f32 else 0

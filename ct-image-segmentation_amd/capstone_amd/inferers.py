@@ -174,7 +174,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Union[Sequence[int]
                 nat.call("ctseg_window_gather", vol.data_ptr(), net.in_channels, *img, a, bb, c, *roi,
                          float(cval), xin.t.data_ptr() + b * win_elems * xin.ld * esz, plan.dt, xin.ld)
         plan.forward()
-        if on_gpu and logits.ld == out_ld:
+        if on_gpu and logits.ld == out_ld and os.environ.get("CTSEG_SW_BLEND", "batch") != "per_window":
             # one output-centric launch for the whole batch: same sums in the same (scan) order, the output read / written once
             b0 = [max(0, min(r[k] for r in rel)) for k in range(3)]
             b1 = [min(img[k], max(r[k] for r in rel) + roi[k]) for k in range(3)]

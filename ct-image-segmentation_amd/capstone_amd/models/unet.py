@@ -92,8 +92,8 @@ class UNet(nn.Module):
             raise NotImplementedError("kernel_size / up_kernel_size other than 3 are not implemented")
         if dimensions not in (2, 3):
             raise ValueError("dimensions must be 2 or 3")
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in ("fp32", "bf16", "fp16"):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16' (inference only)")
         assert len(channels) >= 2 and len(strides) >= len(channels) - 1
         self.dimensions, self.in_channels, self.out_channels = dimensions, in_channels, out_channels
         self.channels, self.strides = list(channels), list(strides)

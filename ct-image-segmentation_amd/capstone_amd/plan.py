@@ -247,8 +247,8 @@ class _Level:
             self.up1 = _ResUnit(plan, up[1], name + ".2.1", rup(up[0].cout, e))
         else:
             self.up0, self.up1 = _ConvBlock(plan, up, name + ".2", rup(ccat, e)), None
-        if plan.dt == BF16 and (self.c1 % e or self.c2 % e):
-            raise nat.NativeError(f"bf16 precision needs channel counts that are multiples of {e} (got {self.c1}, {self.c2})")
+        if nat.is16(plan.dt) and (self.c1 % e or self.c2 % e):
+            raise nat.NativeError(f"16-bit storage needs channel counts that are multiples of {e} (got {self.c1}, {self.c2})")
         if plan.dt == F32 and (self.c1 % e or self.c2 % e):
             raise nat.NativeError(f"channel counts must be multiples of {e} (got {self.c1}, {self.c2})")
 
@@ -298,6 +298,12 @@ class Plan:
         net = engine.net
         self.inference = inference        # forward program only: no gradient buffers, no backward program
         self.engine, self.store, self.dt, self.device = engine, engine.store, engine.dt, engine.device
+        if self.dt == nat.F16 and not inference:
+            # the weight-gradient / norm-backward / loss-gradient kernels exist for bf16 and fp32 storage only: without loss scaling
+            # the gradients of this step underflow in half precision anyway (d loss / d logit ~ 1 / (B * voxels) = 4e-8 at
+            # 2 x 512 x 512 x 48, below the smallest half subnormal 6e-8); bf16 has fp32's range at the same MFMA rate
+            raise nat.NativeError("precision='fp16' (IEEE half storage) is implemented for inference: run under torch.no_grad() / "
+                                  "the sliding-window inferer, and train with precision='bf16' or 'fp32'")
         self.dims = net.dimensions
         self.need_input_grad = False
         self.packer = Packer(self)
@@ -493,7 +499,7 @@ class Engine:
 
     def __init__(self, net):
         self.net = net
-        self.dt = BF16 if net.precision == "bf16" else F32
+        self.dt = nat.DT_OF_PRECISION[net.precision]
         self.store = None
         self.device = None
         self.plans = {}
@@ -559,7 +565,7 @@ class Engine:
         """record a Plan; bf16 tensors of 9..12 channels (the class logits' neighbours) are laid out 12 wide when every pass
         that touches them can move such rows (ctseg_conv_narrow_ok / ctseg_wgrad_narrow_ok), 16 wide otherwise"""
         from . import engine as eng
-        if self.dt == BF16 and os.environ.get("CTSEG_NARROW_ROWS", "1") != "0":
+        if nat.is16(self.dt) and os.environ.get("CTSEG_NARROW_ROWS", "1") != "0":
             eng.NARROW_ROWS[0] = True
             try:
                 return Plan(self, N, *sp, inference=inference)

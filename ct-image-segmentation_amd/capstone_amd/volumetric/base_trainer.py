@@ -92,8 +92,14 @@ SEED = 12342
 
 
 def _precision(kwargs):
-    p = kwargs.get("precision", "fp32")   # Lightning's Trainer flag arrives through **vars(args) too
-    if p in (16, "16", "bf16", "bf16-mixed", "16-mixed"):
+    """Lightning's Trainer flag arrives through **vars(args) too.  ``--precision 16`` is IEEE half, as in the reference's stack
+    (Lightning 1.0 native AMP): here that is fp16 STORAGE for the inference passes (validation / test / sliding window); a
+    training step in it raises with the reason (no loss scaling; bf16 is the 16-bit training dtype).  Nothing is remapped
+    silently: "bf16" has to be asked for by name."""
+    p = kwargs.get("precision", "fp32")
+    if p in (16, "16", "fp16", "16-mixed", "16-true"):
+        return "fp16"
+    if p in ("bf16", "bf16-mixed", "bf16-true"):
         return "bf16"
     if p in (32, "32", "fp32", "32-true", None):
         return "fp32"

@@ -21,6 +21,7 @@ struct ConvKArgs {
   // split output (ctseg_conv_desc::out2): columns >= out2_col0 go to out2; stem and stride-2 halo kernels only
   char* out2;
   int out2_col0, o2_ld;
+  int dtype;       // CTSEG_F32 / CTSEG_BF16 / CTSEG_F16 storage of the pass (the launchers pick the instantiation from it)
   int xcd_order;   // generic / ring kernels: grid.x = 8 * ceil(tiles*N / 8), workgroup L takes tile (L&7)*chunk + (L>>3)
 };
 
@@ -37,6 +38,9 @@ template <> __device__ __forceinline__ void mma16<BF16>(f32x4& acc, const u32x4&
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, xfrag), acc,
                                                 0, 0, 0);
 }
+template <> __device__ __forceinline__ void mma16<F16>(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wfrag), __builtin_bit_cast(f16x8, xfrag), acc, 0, 0, 0);
+}
 template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& wfrag, const u32x4& xfrag) {
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -52,6 +56,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
                                               const int* sRow, f32x4 (&acc)[BN / WGN / 16][BM / WGM / 16], int n, int tile,
                                               int cls_index, int col0) {
   constexpr int SZ = TT<T>::SZ, NTHR = 64 * WGM * WGN;
+  using H = typename TT<T>::H;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, MT = WTM / 16, NT = WTN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -85,7 +90,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
       if (of32 || SZ == 4) {
         *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
       } else {
-        *reinterpret_cast<u32x2*>(cp) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(cp) = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
       }
     }
   }
@@ -157,17 +162,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
           *reinterpret_cast<u32x4*>(op[u]) = *reinterpret_cast<const u32x4*>(cp[u]);
         } else {
           float v[8], a[8];
-          load_n_as_float(cp[u], of32 || SZ == 4, EPO, v);
+          load_n_as_float<H>(cp[u], of32 || SZ == 4, EPO, v);
           if (af32 || SZ == 4) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a[e] = __uint_as_float(a0[u][e]); a[4 + e] = __uint_as_float(a1[u][e]); }
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a[2 * e] = bf2f(a0[u][e] & 0xffffu); a[2 * e + 1] = bf2f(a0[u][e] >> 16); }
+            for (int e = 0; e < 4; ++e) { a[2 * e] = h2f<H>(a0[u][e] & 0xffffu); a[2 * e + 1] = h2f<H>(a0[u][e] >> 16); }
           }
           for (int e = 0; e < EPO; ++e) v[e] += a[e];
           if (of32 || SZ == 4) store_chunk<float>(op[u], v);
-          else store_chunk<BF16>(op[u], v);
+          else store_chunk<H>(op[u], v);
         }
       }
     }

@@ -42,7 +42,7 @@ struct DownGeom {
   int tbn, tcn, tiles;
 };
 
-template <int VB, bool STATS>
+template <typename H, int VB, bool STATS>     // H = 16-bit storage kind (BF16 / F16)
 __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs P, const DownGeom G, int total_tiles) {
   using CF = DownCfg<VB>;
   constexpr int TA = CF::TA, HA = CF::HA, NPL = CF::NPL, PLANE = CF::PLANE, CG = CF::CG, RG = CF::G;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-              for (int j = 0; j < NT; ++j) mma16<BF16>(acc[rt][j], wf[j], xf[rt]);
+              for (int j = 0; j < NT; ++j) mma16<H>(acc[rt][j], wf[j], xf[rt]);
           }
         }
       }
@@ -292,12 +292,12 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
             if (af32) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap); v[0] += a4[0]; v[1] += a4[1]; v[2] += a4[2]; v[3] += a4[3]; }
             else {
               const u32x2 w2 = *reinterpret_cast<const u32x2*>(ap);
-              v[0] += bf2f(w2[0] & 0xffffu); v[1] += bf2f(w2[0] >> 16); v[2] += bf2f(w2[1] & 0xffffu); v[3] += bf2f(w2[1] >> 16);
+              v[0] += h2f<H>(w2[0] & 0xffffu); v[1] += h2f<H>(w2[0] >> 16); v[2] += h2f<H>(w2[1] & 0xffffu); v[3] += h2f<H>(w2[1] >> 16);
             }
           }
           char* op = (P.out2 != nullptr && ch >= P.out2_col0) ? P.out2 + (vox * P.o2_ld + (ch - P.out2_col0)) * 2
                                                                : P.out + (vox * P.o_ld + ch) * 2;
-          *reinterpret_cast<u32x2*>(op) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(op) = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
         }
       }
     }
@@ -330,7 +330,7 @@ static void down_geom(const ConvKArgs& a, int vb, DownGeom& g) {
 }
 
 bool conv_down_halo_eligible(const ConvKArgs& a, int dtype, int nclass) {
-  if (dtype != CTSEG_BF16 || a.out_f32 || nclass != 1 || a.sin != 2 || a.sout != 1) return false;
+  if (!is16(dtype) || a.out_f32 || nclass != 1 || a.sin != 2 || a.sout != 1) return false;
   const int vb = a.Cg * 2;
   // 32 gathered channels -> 128 columns was measured SLOWER than the generic kernel (128-row tiles do not amortise the 221 KB
   // weight stream): only the 16-channel case runs here
@@ -369,8 +369,13 @@ void launch_conv_down_halo(ConvKArgs& a, hipStream_t st) {
   const int total = g.tiles * a.N;
   const dim3 grid((unsigned)down_grid(a, g), (unsigned)((a.Cn + DH_CN - 1) / DH_CN)), blk(DH_NTHR);
   const bool stats = a.stats != nullptr;
-  if (stats) hipLaunchKernelGGL((conv_down_halo_kernel<32, true>), grid, blk, 0, st, a, g, total);
-  else hipLaunchKernelGGL((conv_down_halo_kernel<32, false>), grid, blk, 0, st, a, g, total);
+  if (a.dtype == CTSEG_F16) {
+    if (stats) hipLaunchKernelGGL((conv_down_halo_kernel<F16, 32, true>), grid, blk, 0, st, a, g, total);
+    else hipLaunchKernelGGL((conv_down_halo_kernel<F16, 32, false>), grid, blk, 0, st, a, g, total);
+  } else {
+    if (stats) hipLaunchKernelGGL((conv_down_halo_kernel<BF16, 32, true>), grid, blk, 0, st, a, g, total);
+    else hipLaunchKernelGGL((conv_down_halo_kernel<BF16, 32, false>), grid, blk, 0, st, a, g, total);
+  }
 }
 
 }  // namespace ctseg

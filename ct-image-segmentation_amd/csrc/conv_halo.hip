@@ -48,6 +48,7 @@ template <int VB, int NT> struct HaloCfg {
 template <typename T, int VB, int NT, bool STATS, bool ADDC>
 __global__ __launch_bounds__((HaloCfg<VB, NT>::NTHR)) void conv_halo_kernel(const ConvKArgs P, int total_tiles, int tyn, int tzn) {
   constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
+  using H = typename TT<T>::H;
   using CF = HaloCfg<VB, NT>;
   constexpr int NPL = CF::NPL, BN = CF::BN, KC = CF::KC, NSTG = CF::NSTG;
   constexpr int NW = CF::NW, NTHR = CF::NTHR, RT = CF::RT;
@@ -273,14 +274,14 @@ __global__ __launch_bounds__((HaloCfg<VB, NT>::NTHR)) void conv_halo_kernel(cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(av[j][i][e]);
           } else {
-            v[0] += bf2f(av[j][i][0] & 0xffffu); v[1] += bf2f(av[j][i][0] >> 16);
-            v[2] += bf2f(av[j][i][1] & 0xffffu); v[3] += bf2f(av[j][i][1] >> 16);
+            v[0] += h2f<H>(av[j][i][0] & 0xffffu); v[1] += h2f<H>(av[j][i][0] >> 16);
+            v[2] += h2f<H>(av[j][i][1] & 0xffffu); v[3] += h2f<H>(av[j][i][1] >> 16);
           }
         }
         if (rv[i] && ch < P.Cn_store) {
           char* op = ob + ((int64_t)ovox[i] * P.o_ld + ch) * OSZ;
           if (OSZ == 4) *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-          else *reinterpret_cast<u32x2*>(op) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          else *reinterpret_cast<u32x2*>(op) = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
         }
       }
     }
@@ -382,6 +383,9 @@ void launch_conv_halo(ConvKArgs& a, int dtype, hipStream_t st) {
   if (dtype == CTSEG_F32) {
     if (vb == 64) { if (n2) launch_halo<float, 64, 2>(a, st); else launch_halo<float, 64, 1>(a, st); }
     else { if (n2) launch_halo<float, 32, 2>(a, st); else launch_halo<float, 32, 1>(a, st); }
+  } else if (dtype == CTSEG_F16) {
+    if (vb == 64) { if (n2) launch_halo<F16, 64, 2>(a, st); else launch_halo<F16, 64, 1>(a, st); }
+    else { if (n2) launch_halo<F16, 32, 2>(a, st); else launch_halo<F16, 32, 1>(a, st); }
   } else {
     if (vb == 64) { if (n2) launch_halo<BF16, 64, 2>(a, st); else launch_halo<BF16, 64, 1>(a, st); }
     else { if (n2) launch_halo<BF16, 32, 2>(a, st); else launch_halo<BF16, 32, 1>(a, st); }

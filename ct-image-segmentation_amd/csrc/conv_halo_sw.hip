@@ -45,7 +45,7 @@ __device__ __forceinline__ void sw_patch_voxel(int r16, int& db, int& c) {
   c = (int)((0x2104765437653210ull >> (4 * r16)) & 7ull);
 }
 
-template <int VB, bool UP, bool STATS>
+template <typename H, int VB, bool UP, bool STATS>     // H = 16-bit storage kind (BF16 / F16)
 __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P, const SwGeom G, int total_tiles) {
   using CF = SwCfg<VB>;
   constexpr int TA = CF::TA, NPL = CF::NPL, PLANE = CF::PLANE, CN = CF::CN, NT = CF::NT, RT = CF::RT, KS = CF::KS;
@@ -222,10 +222,10 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
             if (af32) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap); v[0] += a4[0]; v[1] += a4[1]; v[2] += a4[2]; v[3] += a4[3]; }
             else {
               const u32x2 w2 = *reinterpret_cast<const u32x2*>(ap);
-              v[0] += bf2f(w2[0] & 0xffffu); v[1] += bf2f(w2[0] >> 16); v[2] += bf2f(w2[1] & 0xffffu); v[3] += bf2f(w2[1] >> 16);
+              v[0] += h2f<H>(w2[0] & 0xffffu); v[1] += h2f<H>(w2[0] >> 16); v[2] += h2f<H>(w2[1] & 0xffffu); v[3] += h2f<H>(w2[1] >> 16);
             }
           }
-          *reinterpret_cast<u32x2*>(P.out + (vox * P.o_ld + ch) * 2) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(P.out + (vox * P.o_ld + ch) * 2) = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
         }
       }
     }
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) mma16<BF16>(acc[rt][j], wf[j], xf[rt]);
+            for (int j = 0; j < NT; ++j) mma16<H>(acc[rt][j], wf[j], xf[rt]);
         }
         if constexpr (UP) {
           const int cl = sTab[96 + tap];
@@ -330,7 +330,7 @@ static bool sw_geom(const ConvKArgs& a, int vb, SwGeom& g) {
 }
 
 bool conv_halo_sw_eligible(const ConvKArgs& a, int dtype, int nclass) {
-  if (dtype != CTSEG_BF16 || a.out_f32 || a.sin != 1) return false;
+  if (!is16(dtype) || a.out_f32 || a.sin != 1) return false;
   const int vb = a.Cg * 2;
   if (!((vb == 128 && a.Cn == 64) || (vb == 256 && a.Cn == 32)) || a.Cn_store != a.Cn) return false;
   if ((a.g_ld % 8) != 0 || ((uintptr_t)a.in % 16) != 0 || ((uintptr_t)a.w % 16) != 0) return false;
@@ -378,7 +378,11 @@ void launch_conv_halo_sw(ConvKArgs& a, int nclass, hipStream_t st) {
   const int total = g.tiles * a.N;
   const dim3 grid((unsigned)sw_grid(a, g)), blk(SW_NTHR);
   const bool up = nclass == 8, stats = a.stats != nullptr;
-#define CTSEG_SW_LAUNCH(VB, UP, ST) hipLaunchKernelGGL((conv_halo_sw_kernel<VB, UP, ST>), grid, blk, 0, st, a, g, total)
+#define CTSEG_SW_LAUNCH(VB, UP, ST)                                                                                      \
+  do {                                                                                                                  \
+    if (a.dtype == CTSEG_F16) hipLaunchKernelGGL((conv_halo_sw_kernel<F16, VB, UP, ST>), grid, blk, 0, st, a, g, total); \
+    else hipLaunchKernelGGL((conv_halo_sw_kernel<BF16, VB, UP, ST>), grid, blk, 0, st, a, g, total);                     \
+  } while (0)
   if (vb == 128) {
     if (up) { if (stats) CTSEG_SW_LAUNCH(128, true, true); else CTSEG_SW_LAUNCH(128, true, false); }
     else { if (stats) CTSEG_SW_LAUNCH(128, false, true); else CTSEG_SW_LAUNCH(128, false, false); }

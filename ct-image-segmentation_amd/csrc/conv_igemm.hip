@@ -284,7 +284,7 @@ static int launch_cfg(const ConvKArgs& a, bool smallc, int nclass, hipStream_t s
 // 65..128 columns take the 192 x 128 tile of the ring-pipelined kernel where it is eligible (Cg a multiple of 32 ...): 256
 // tiles for the 49152-row layers instead of 384 tiles of 128 rows (1.5 rounds over the 256 CUs).
 static int tile_rows_for(const ConvKArgs& a, int dtype, bool smallc, int nclass) {
-  if (dtype == CTSEG_BF16 && !a.out_f32 && !smallc) {
+  if (is16(dtype) && !a.out_f32 && !smallc) {
     if (a.Cn > 128) return 192;
     // (not for 32 gathered channels: those passes are operand-traffic bound with short K loops; measured 0.21 -> 0.24 ms)
     if (a.Cn > 64 && a.Cg >= 64 && conv_ring_eligible(a, dtype, nclass)) return 192;
@@ -298,9 +298,9 @@ template <typename T> static int launch_dtype(ConvKArgs& a, bool smallc, int ncl
   // XCD-contiguous tile ranges: measured neutral for single-class passes (their halo re-reads already hit L2 / Infinity Cache),
   // 7-9 % on the 8-class passes (384->64 and 256->64), where every class re-gathers the same input tile
   a.xcd_order = nclass > 1 ? 1 : 0;
-  if constexpr (TT<T>::DT == CTSEG_BF16) {
+  if constexpr (TT<T>::SZ == 2) {
     if (bm == 192) {
-      if (conv_ring_eligible(a, CTSEG_BF16, nclass)) { launch_conv_ring(a, nclass, st); return 0; }
+      if (conv_ring_eligible(a, TT<T>::DT, nclass)) { launch_conv_ring(a, nclass, st); return 0; }
       return launch_cfg<T, 192, 256, 2, 4>(a, false, nclass, st);
     }
   }
@@ -319,7 +319,7 @@ extern "C" int ctseg_conv_tile_cols(int32_t Cn) { return Cn <= 16 ? 16 : Cn <= 3
 
 extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   CTSEG_REQUIRE(d != nullptr && d->in && d->w && d->out, "conv_igemm: null pointer");
-  CTSEG_REQUIRE(d->dtype == CTSEG_F32 || d->dtype == CTSEG_BF16, "conv_igemm: bad dtype %d", d->dtype);
+  CTSEG_REQUIRE(d->dtype == CTSEG_F32 || is16(d->dtype), "conv_igemm: bad dtype %d", d->dtype);
   const int SZ = d->dtype == CTSEG_F32 ? 4 : 2, EPC = 16 / SZ, BK = 128 / SZ;
   const int OSZ = d->out_f32 ? 4 : SZ, EPO = 16 / OSZ;
   CTSEG_REQUIRE(d->nclass >= 1 && d->nclass <= CTSEG_MAX_CLASSES, "conv_igemm: nclass %d", d->nclass);
@@ -374,6 +374,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   a.stats_ld = d->stats_ld; a.stats_tiles = d->stats_tiles; a.stats_tile0 = d->stats_tile0;
   for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
   a.out2 = (char*)d->out2; a.out2_col0 = d->out2_col0; a.o2_ld = d->o2_ld; a.xcd_order = 0;
+  a.dtype = d->dtype;
   const bool halo = conv_halo_eligible(a, d->dtype, d->nclass);
   const bool up = !halo && conv_up_eligible(a, d->dtype, d->nclass);
   const bool stem = !halo && !up && conv_stem_eligible(a, d->dtype, d->nclass);
@@ -410,13 +411,14 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   else if (sw) launch_conv_halo_sw(a, d->nclass, st);
   else if (down) launch_conv_down_halo(a, st);
   else if (d->dtype == CTSEG_F32) launch_dtype<float>(a, smallc, d->nclass, st);
+  else if (d->dtype == CTSEG_F16) launch_dtype<F16>(a, smallc, d->nclass, st);
   else launch_dtype<BF16>(a, smallc, d->nclass, st);
   CTSEG_LAUNCH_CHECK("conv_igemm");
   return 0;
 }
 
 static void fill_args(const ctseg_conv_desc* d, ConvKArgs& a) {
-  a.out2 = nullptr; a.out2_col0 = 0; a.o2_ld = 0; a.xcd_order = 0;
+  a.out2 = nullptr; a.out2_col0 = 0; a.o2_ld = 0; a.xcd_order = 0; a.dtype = d->dtype;
   a.w = (const char*)d->w; a.Cn_store = d->Cn_store;
   a.in = (const char*)d->in; a.N = d->N; a.Xi = d->Xi; a.Yi = d->Yi; a.Zi = d->Zi; a.Xr = d->Xr; a.Yr = d->Yr; a.Zr = d->Zr;
   a.Cg = d->Cg; a.Cn = d->Cn; a.g_ld = d->g_ld; a.sin = d->sin; a.sout = d->sout; a.rows = d->Xr * d->Yr * d->Zr;
@@ -437,7 +439,7 @@ extern "C" int ctseg_conv_split_ok(const ctseg_conv_desc* d) {
 // 1 when this pass may read / write 12-wide bf16 rows (g_ld, o_ld / Cn_store, add_ld of the descriptor): it is taken by
 // the resident-weight LDS-halo kernel (any of them narrow) or by the stride-2 "up" kernel (narrow output / addend only)
 extern "C" int ctseg_conv_narrow_ok(const ctseg_conv_desc* d) {
-  if (d == nullptr || d->dtype != CTSEG_BF16 || d->nclass < 1) return 0;
+  if (d == nullptr || !is16(d->dtype) || d->nclass < 1) return 0;
   ConvKArgs a;
   fill_args(d, a);
   a.out_f32 = d->out_f32; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo; a.add = (const char*)d->add; a.o_ld = d->o_ld;

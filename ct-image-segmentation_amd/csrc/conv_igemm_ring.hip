@@ -57,7 +57,7 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p, uint32_t bytes) {
 }
 
 // NA = 16-row blocks of the gathered operand this wave fetches per stage (12 blocks over 8 waves: 2 for waves 0-3, 1 for 4-7)
-template <int BN, int NA>
+template <typename H, int BN, int NA>
 __device__ __forceinline__ void ring_main(const ConvKArgs& P, const ctseg_conv_class& K, char* smem, const int* sRow, const int* sTap,
                                           f32x4 (&acc)[4][RingCfgT<BN>::BM / RingCfgT<BN>::WGM / 16], int n, int col0, int wave,
                                           int lane) {
@@ -132,7 +132,7 @@ __device__ __forceinline__ void ring_main(const ConvKArgs& P, const ctseg_conv_c
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) mma16<BF16>(acc[j][i], w[j], x[i]);
+      for (int i = 0; i < MT; ++i) mma16<H>(acc[j][i], w[j], x[i]);
   };
   constexpr int CNT = NA + NB;     // this wave's loads per stage
 
@@ -174,7 +174,7 @@ __device__ __forceinline__ void ring_main(const ConvKArgs& P, const ctseg_conv_c
   static_assert(D == 5, "the drain above is written for a five-deep ring");
 }
 
-template <int BN>
+template <typename H, int BN>     // H = 16-bit storage kind (BF16 / F16): the only difference is the MFMA and the epilogue's conversions
 __global__ __launch_bounds__(512) void conv_igemm_ring_kernel(const ConvKArgs P) {
   using C = RingCfgT<BN>;
   constexpr int BM = C::BM, MT = BM / C::WGM / 16;
@@ -224,15 +224,15 @@ __global__ __launch_bounds__(512) void conv_igemm_ring_kernel(const ConvKArgs P)
     for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // the two halves of the workgroup run the same schedule with a different (compile-time) number of loads per stage
-  if (wave < 4) ring_main<BN, 2>(P, K, smem, sRow, sTap, acc, n, col0, wave, lane);
-  else ring_main<BN, 1>(P, K, smem, sRow, sTap, acc, n, col0, wave, lane);
+  if (wave < 4) ring_main<H, BN, 2>(P, K, smem, sRow, sTap, acc, n, col0, wave, lane);
+  else ring_main<H, BN, 1>(P, K, smem, sRow, sTap, acc, n, col0, wave, lane);
   __syncthreads();
 
-  conv_epilogue<BF16, BM, BN, C::WGM, C::WGN>(P, K, smem, sStats, sRow, acc, n, tile, (int)blockIdx.z, col0);
+  conv_epilogue<H, BM, BN, C::WGM, C::WGN>(P, K, smem, sStats, sRow, acc, n, tile, (int)blockIdx.z, col0);
 }
 
 bool conv_ring_eligible(const ConvKArgs& a, int dtype, int nclass) {
-  if (dtype != CTSEG_BF16 || a.out_f32 || a.Cn <= 64 || a.Cg % 32 != 0) return false;
+  if (!is16(dtype) || a.out_f32 || a.Cn <= 64 || a.Cg % 32 != 0) return false;
   if ((int64_t)a.N * a.Xi * a.Yi * a.Zi * a.g_ld * 2 >= (int64_t)1 << 31) return false;   // 32-bit buffer offsets
   for (int c = 0; c < nclass; ++c)
     if (a.cls[c].kpad % 64 != 0 || a.cls[c].kpad < 256 || a.cls[c].ntaps > 32 || a.cls[c].kpad < a.cls[c].ntaps * a.Cg ||
@@ -245,10 +245,12 @@ void launch_conv_ring(const ConvKArgs& a, int nclass, hipStream_t st) {
   const int gx = a.xcd_order ? 8 * ((a.tiles * a.N + 7) / 8) : a.tiles * a.N;
   if (a.Cn > 128) {
     dim3 grid((unsigned)gx, (unsigned)((a.Cn + 255) / 256), (unsigned)nclass);
-    hipLaunchKernelGGL(conv_igemm_ring_kernel<256>, grid, dim3(512), 0, st, a);
+    if (a.dtype == CTSEG_F16) hipLaunchKernelGGL((conv_igemm_ring_kernel<F16, 256>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_ring_kernel<BF16, 256>), grid, dim3(512), 0, st, a);
   } else {
     dim3 grid((unsigned)gx, 1u, (unsigned)nclass);
-    hipLaunchKernelGGL(conv_igemm_ring_kernel<128>, grid, dim3(512), 0, st, a);
+    if (a.dtype == CTSEG_F16) hipLaunchKernelGGL((conv_igemm_ring_kernel<F16, 128>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_ring_kernel<BF16, 128>), grid, dim3(512), 0, st, a);
   }
 }
 

@@ -62,7 +62,7 @@ __device__ __forceinline__ int stem_tap_off(int t) {
   return (tx * S_IY + ty) * S_PZ + tz;
 }
 
-template <int NT, bool STATS>
+template <typename H, int NT, bool STATS>     // H = 16-bit storage kind (BF16 / F16)
 __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, int total_tiles, StemGeom G) {
   constexpr int BN = 16 * NT;
   __shared__ __attribute__((aligned(16))) char smem[2 * S_INB + 4 * 2 * BN * 4];
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        mma16<BF16>(acc, wf[j], xf);
+        mma16<H>(acc, wf[j], xf);
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
         if (rv && ch < P.Cn_store) {
           char* op = (ob2 != nullptr && ch >= P.out2_col0) ? ob2 + ((int64_t)ovox[i] * P.o2_ld + (ch - P.out2_col0)) * 2
                                                           : ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2;
-          *reinterpret_cast<u32x2*>(op) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(op) = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
         }
       }
     }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
 }
 
 bool conv_stem_eligible(const ConvKArgs& a, int dtype, int nclass) {
-  if (dtype != CTSEG_BF16 || nclass != 1 || a.Cg != 1 || a.g_ld != 1 || a.sin != 2 || a.sout != 1 || a.out_f32 || a.add) return false;
+  if (!is16(dtype) || nclass != 1 || a.Cg != 1 || a.g_ld != 1 || a.sin != 2 || a.sout != 1 || a.out_f32 || a.add) return false;
   if (a.cls[0].ntaps != 27 || a.cls[0].kpad != 64 || a.Cn > 64 || a.Cn % 16 != 0 || a.Zr < 4) return false;
   if (a.Xi != 2 * a.Xr || a.Yi != 2 * a.Yr || a.Zi != 2 * a.Zr) return false;
   if ((int64_t)a.Xi * a.Yi * a.Zi >= (1ll << 31) || (int64_t)a.Xo * a.Yo * a.Zo * a.o_ld * 2 >= (1ll << 31)) return false;
@@ -226,8 +226,11 @@ void launch_conv_stem(ConvKArgs& a, hipStream_t st) {
   const int nt = (a.Cn + 15) / 16;
 #define CTSEG_STEM(NTV)                                                                                               \
   do {                                                                                                              \
-    if (a.stats != nullptr) hipLaunchKernelGGL((conv_stem_fwd_kernel<NTV, true>), dim3(grid), dim3(256), 0, st, a, total, g); \
-    else hipLaunchKernelGGL((conv_stem_fwd_kernel<NTV, false>), dim3(grid), dim3(256), 0, st, a, total, g);          \
+    if (a.dtype == CTSEG_F16) {                                                                                       \
+      if (a.stats != nullptr) hipLaunchKernelGGL((conv_stem_fwd_kernel<F16, NTV, true>), dim3(grid), dim3(256), 0, st, a, total, g); \
+      else hipLaunchKernelGGL((conv_stem_fwd_kernel<F16, NTV, false>), dim3(grid), dim3(256), 0, st, a, total, g);    \
+    } else if (a.stats != nullptr) hipLaunchKernelGGL((conv_stem_fwd_kernel<BF16, NTV, true>), dim3(grid), dim3(256), 0, st, a, total, g); \
+    else hipLaunchKernelGGL((conv_stem_fwd_kernel<BF16, NTV, false>), dim3(grid), dim3(256), 0, st, a, total, g);     \
   } while (0)
   if (nt == 1) CTSEG_STEM(1);
   else if (nt == 2) CTSEG_STEM(2);

@@ -29,7 +29,7 @@ template <int VB> struct UpCfg {
   static constexpr int TOTAL = WBYTES + 2048 + HALO + 8 * 2 * 16 * 4 + 64 * 4 + 16 * 4;
 };
 
-template <int VB>
+template <typename H, int VB>     // H = 16-bit storage kind (BF16 / F16)
 __global__ __launch_bounds__(512) void conv_up_halo_kernel(const ConvKArgs P, int total_tiles, int tyn, int tzn) {
   using CF = UpCfg<VB>;
   constexpr int NPL = CF::NPL, CPT = VB / 64;           // 64-byte K chunks per tap
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512) void conv_up_halo_kernel(const ConvKArgs P, in
           for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sH + abase[i] + kc * 4 * U_PLANE + delta);
           const u32x4 wf = *reinterpret_cast<const u32x4*>(wc + (ci >> 1) * (16 * 128) + (((4 * (ci & 1) + q4) ^ wswz) << 4));
 #pragma unroll
-          for (int i = 0; i < 4; ++i) mma16<BF16>(acc[i], wf, xf[i]);
+          for (int i = 0; i < 4; ++i) mma16<H>(acc[i], wf, xf[i]);
         }
       }
       // epilogue of this class: output voxel = 2*voxel + (ox,oy,oz)
@@ -208,10 +208,10 @@ __global__ __launch_bounds__(512) void conv_up_halo_kernel(const ConvKArgs P, in
             if (af32) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap); v[0] += a4[0]; v[1] += a4[1]; v[2] += a4[2]; v[3] += a4[3]; }
             else {
               const u32x2 w2 = *reinterpret_cast<const u32x2*>(ap);
-              v[0] += bf2f(w2[0] & 0xffffu); v[1] += bf2f(w2[0] >> 16); v[2] += bf2f(w2[1] & 0xffffu); v[3] += bf2f(w2[1] >> 16);
+              v[0] += h2f<H>(w2[0] & 0xffffu); v[1] += h2f<H>(w2[0] >> 16); v[2] += h2f<H>(w2[1] & 0xffffu); v[3] += h2f<H>(w2[1] >> 16);
             }
           }
-          *reinterpret_cast<u32x2*>(ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2) = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
         }
       }
     };
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512) void conv_up_halo_kernel(const ConvKArgs P, in
 }
 
 bool conv_up_eligible(const ConvKArgs& a, int dtype, int nclass) {
-  if (dtype != CTSEG_BF16 || nclass != 8 || a.sin != 1 || a.sout != 2 || a.out_f32) return false;
+  if (!is16(dtype) || nclass != 8 || a.sin != 1 || a.sout != 2 || a.out_f32) return false;
   const int vb = a.Cg * 2;
   if (!(vb == 64 || vb == 128) || a.Cn > 16) return false;
   if ((a.g_ld % 8) != 0 || ((uintptr_t)a.in % 16) != 0) return false;
@@ -295,8 +295,13 @@ void launch_conv_up(ConvKArgs& a, hipStream_t st) {
   const int total = a.tiles * a.N;
   const int vb = a.Cg * 2;
   const int gx = up_grid(a);
-  if (vb == 128) hipLaunchKernelGGL((conv_up_halo_kernel<128>), dim3(gx), dim3(512), 0, st, a, total, tyn, tzn);
-  else hipLaunchKernelGGL((conv_up_halo_kernel<64>), dim3(gx), dim3(512), 0, st, a, total, tyn, tzn);
+  if (a.dtype == CTSEG_F16) {
+    if (vb == 128) hipLaunchKernelGGL((conv_up_halo_kernel<F16, 128>), dim3(gx), dim3(512), 0, st, a, total, tyn, tzn);
+    else hipLaunchKernelGGL((conv_up_halo_kernel<F16, 64>), dim3(gx), dim3(512), 0, st, a, total, tyn, tzn);
+  } else {
+    if (vb == 128) hipLaunchKernelGGL((conv_up_halo_kernel<BF16, 128>), dim3(gx), dim3(512), 0, st, a, total, tyn, tzn);
+    else hipLaunchKernelGGL((conv_up_halo_kernel<BF16, 64>), dim3(gx), dim3(512), 0, st, a, total, tyn, tzn);
+  }
 }
 
 }  // namespace ctseg

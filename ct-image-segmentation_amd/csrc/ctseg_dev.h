@@ -13,13 +13,17 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 struct BF16 {};  // storage tag: 16-bit brain float kept as raw ushort
+struct F16 {};   // storage tag: IEEE half kept as raw ushort (forward / inference passes only)
 
 template <typename T> struct TT;
-template <> struct TT<float> { static constexpr int SZ = 4, EPC = 4, DT = CTSEG_F32; };
-template <> struct TT<BF16> { static constexpr int SZ = 2, EPC = 8, DT = CTSEG_BF16; };
+// H = the 16-bit storage kind whose conversions a kernel body names in branches that are dead for fp32 storage
+template <> struct TT<float> { static constexpr int SZ = 4, EPC = 4, DT = CTSEG_F32; using H = BF16; };
+template <> struct TT<BF16> { static constexpr int SZ = 2, EPC = 8, DT = CTSEG_BF16; using H = BF16; };
+template <> struct TT<F16> { static constexpr int SZ = 2, EPC = 8, DT = CTSEG_F16; using H = F16; };
 
 __device__ __forceinline__ float bf2f(uint32_t u16) { return __uint_as_float(u16 << 16); }
 __device__ __forceinline__ uint32_t f2bf(float x) {
@@ -27,6 +31,21 @@ __device__ __forceinline__ uint32_t f2bf(float x) {
   return (uint32_t)__builtin_bit_cast(unsigned short, b);
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+
+// 16-bit storage kind H (BF16 / F16): element <-> float.  Half stores saturate at +-65504 instead of overflowing to inf (a
+// convolution output ahead of its InstanceNorm may be large; its statistics are taken from the fp32 accumulators anyway).
+template <typename H> __device__ __forceinline__ float h2f(uint32_t u16);
+template <> __device__ __forceinline__ float h2f<BF16>(uint32_t u16) { return bf2f(u16); }
+template <> __device__ __forceinline__ float h2f<F16>(uint32_t u16) {
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)u16);
+}
+template <typename H> __device__ __forceinline__ uint32_t f2h(float x);
+template <> __device__ __forceinline__ uint32_t f2h<BF16>(float x) { return f2bf(x); }
+template <> __device__ __forceinline__ uint32_t f2h<F16>(float x) {
+  const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);   // RNE; NaN passes through fmed3 as NaN
+  return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+template <typename H> __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f2h<H>(lo) | (f2h<H>(hi) << 16); }
 
 // Load / store EPC<T> consecutive elements (one 16-byte chunk) as floats.
 template <typename T> __device__ __forceinline__ void load_chunk(const char* p, float* v);
@@ -38,6 +57,11 @@ template <> __device__ __forceinline__ void load_chunk<BF16>(const char* p, floa
   u32x4 t = *reinterpret_cast<const u32x4*>(p);
 #pragma unroll
   for (int i = 0; i < 4; ++i) { v[2 * i] = bf2f(t[i] & 0xffffu); v[2 * i + 1] = bf2f(t[i] >> 16); }
+}
+template <> __device__ __forceinline__ void load_chunk<F16>(const char* p, float* v) {
+  u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = h2f<F16>(t[i] & 0xffffu); v[2 * i + 1] = h2f<F16>(t[i] >> 16); }
 }
 template <typename T> __device__ __forceinline__ void store_chunk(char* p, const float* v);
 template <> __device__ __forceinline__ void store_chunk<float>(char* p, const float* v) {
@@ -51,23 +75,32 @@ template <> __device__ __forceinline__ void store_chunk<BF16>(char* p, const flo
   *reinterpret_cast<u32x4*>(p) = t;
 }
 
+template <> __device__ __forceinline__ void store_chunk<F16>(char* p, const float* v) {
+  u32x4 t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = pack2<F16>(v[2 * i], v[2 * i + 1]);
+  *reinterpret_cast<u32x4*>(p) = t;
+}
+
 // EP consecutive elements as floats: EP = EPC<T> (one 16-byte chunk) or, for bf16 rows whose stride is an odd multiple of
 // 4 elements (10 classes stored 12 wide: 24-byte rows), EP = 4 (an 8-byte chunk; rows are then only 8-byte aligned)
 template <typename T, int EP> __device__ __forceinline__ void load_ep(const char* p, float* v) {
   if constexpr (EP == TT<T>::EPC) {
     load_chunk<T>(p, v);
   } else {
-    static_assert(EP == 4 && TT<T>::SZ == 2, "half chunks exist for bf16 only");
+    static_assert(EP == 4 && TT<T>::SZ == 2, "half chunks exist for 16-bit storage only");
+    using H = typename TT<T>::H;
     const u32x2 t = *reinterpret_cast<const u32x2*>(p);
-    v[0] = bf2f(t[0] & 0xffffu); v[1] = bf2f(t[0] >> 16); v[2] = bf2f(t[1] & 0xffffu); v[3] = bf2f(t[1] >> 16);
+    v[0] = h2f<H>(t[0] & 0xffffu); v[1] = h2f<H>(t[0] >> 16); v[2] = h2f<H>(t[1] & 0xffffu); v[3] = h2f<H>(t[1] >> 16);
   }
 }
 template <typename T, int EP> __device__ __forceinline__ void store_ep(char* p, const float* v) {
   if constexpr (EP == TT<T>::EPC) {
     store_chunk<T>(p, v);
   } else {
-    static_assert(EP == 4 && TT<T>::SZ == 2, "half chunks exist for bf16 only");
-    *reinterpret_cast<u32x2*>(p) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    static_assert(EP == 4 && TT<T>::SZ == 2, "half chunks exist for 16-bit storage only");
+    using H = typename TT<T>::H;
+    *reinterpret_cast<u32x2*>(p) = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
   }
 }
 
@@ -81,15 +114,15 @@ __device__ __forceinline__ u32x4 load_row12_chunk(const char* p, bool second) {
   return u32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
-// n consecutive elements of runtime dtype -> floats (n = 4 or 8; pointer aligned to n*size)
-__device__ __forceinline__ void load_n_as_float(const char* p, bool is_f32, int n, float* v) {
+// n consecutive elements, fp32 or 16-bit kind H by a runtime flag -> floats (n = 4 or 8; pointer aligned to n*size)
+template <typename H = BF16> __device__ __forceinline__ void load_n_as_float(const char* p, bool is_f32, int n, float* v) {
   if (is_f32) {
     for (int i = 0; i < n; i += 4) load_chunk<float>(p + 4 * i, v + i);
   } else if (n == 8) {
-    load_chunk<BF16>(p, v);
+    load_chunk<H>(p, v);
   } else {
     u32x2 t = *reinterpret_cast<const u32x2*>(p);
-    v[0] = bf2f(t[0] & 0xffffu); v[1] = bf2f(t[0] >> 16); v[2] = bf2f(t[1] & 0xffffu); v[3] = bf2f(t[1] >> 16);
+    v[0] = h2f<H>(t[0] & 0xffffu); v[1] = h2f<H>(t[0] >> 16); v[2] = h2f<H>(t[1] & 0xffffu); v[3] = h2f<H>(t[1] >> 16);
   }
 }
 
@@ -121,6 +154,8 @@ void set_error(const char* fmt, ...);
       return -2;                                                         \
     }                                                                    \
   } while (0)
+
+static inline bool is16(int dtype) { return dtype == CTSEG_BF16 || dtype == CTSEG_F16; }   // 16-bit storage kinds
 
 static inline int ilog_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

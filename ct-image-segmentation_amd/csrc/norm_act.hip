@@ -472,12 +472,13 @@ using namespace ctseg;
 
 // EPC_ = elements per chunk the launch works in: 16-byte chunks, or 8-byte ones for bf16 when some tensor's channel stride
 // is a multiple of 4 but not of 8 (10 classes stored 12 wide); every stride must then be a multiple of 4
-#define CHECK_CL_(dtype, C, ALLOW_HALF, ...)                                                               \
-  CTSEG_REQUIRE(dtype == CTSEG_F32 || dtype == CTSEG_BF16, "bad dtype");                                   \
+#define CHECK_CL_(dtype, C, ALLOW_HALF, FWD_ONLY_OK, ...)                                                               \
+  CTSEG_REQUIRE(dtype == CTSEG_F32 || dtype == CTSEG_BF16 || (FWD_ONLY_OK && dtype == CTSEG_F16),           \
+                "bad dtype %d (CTSEG_F16 is accepted by the forward pass only)", dtype);                   \
   int EPC_ = dtype == CTSEG_F32 ? 4 : 8;                                                                   \
   {                                                                                                        \
     const int lds_[] = {__VA_ARGS__};                                                                      \
-    if (ALLOW_HALF && dtype == CTSEG_BF16)                                                                 \
+    if (ALLOW_HALF && is16(dtype))                                                                         \
       for (int ld_ : lds_) if (ld_ % 8 != 0) EPC_ = 4;                                                     \
   }                                                                                                        \
   const int Cv = (C + EPC_ - 1) / EPC_;                                                                    \
@@ -485,8 +486,9 @@ using namespace ctseg;
     const int lds_[] = {__VA_ARGS__};                                                                      \
     for (int ld_ : lds_) CTSEG_REQUIRE(ld_ % EPC_ == 0 && ld_ >= Cv * EPC_, "channel stride %d not chunked for C=%d", ld_, C); \
   }
-#define CHECK_CL(dtype, C, ...) CHECK_CL_(dtype, C, false, __VA_ARGS__)
-#define CHECK_CL_HALF(dtype, C, ...) CHECK_CL_(dtype, C, true, __VA_ARGS__)
+#define CHECK_CL(dtype, C, ...) CHECK_CL_(dtype, C, false, false, __VA_ARGS__)
+#define CHECK_CL_HALF(dtype, C, ...) CHECK_CL_(dtype, C, true, false, __VA_ARGS__)
+#define CHECK_CL_HALF_FWD(dtype, C, ...) CHECK_CL_(dtype, C, true, true, __VA_ARGS__)
 
 extern "C" int ctseg_instnorm_finalize(const float* partials, int32_t N, int32_t P, int32_t ld, int32_t col0, int32_t C,
                                        double count, double eps, double* scratch, float* mean_rstd, void* stream) {
@@ -507,7 +509,7 @@ extern "C" int ctseg_instnorm_prelu_fwd(int32_t dtype, const void* y, int32_t y_
                                         const void* res, int32_t res_ld, void* out, int32_t out_ld, int32_t N, int64_t S,
                                         int32_t C, void* stream) {
   CTSEG_REQUIRE(y && out && N > 0 && S > 0 && C > 0, "instnorm_prelu_fwd: bad arguments");
-  CHECK_CL_HALF(dtype, C, y_ld, out_ld, res ? res_ld : y_ld);
+  CHECK_CL_HALF_FWD(dtype, C, y_ld, out_ld, res ? res_ld : y_ld);
   CTSEG_REQUIRE(mean_rstd == nullptr || alpha != nullptr, "instnorm_prelu_fwd: alpha missing");
   dim3 grid(ew_blocks_for(S * Cv, Cv), N);
   const size_t sh = 2 * C * sizeof(float);
@@ -516,6 +518,7 @@ extern "C" int ctseg_instnorm_prelu_fwd(int32_t dtype, const void* y, int32_t y_
   hipLaunchKernelGGL((instnorm_prelu_fwd_kernel<T, EP>), grid, dim3(256), sh, st, (const char*)y, y_ld, mean_rstd, alpha,     \
                      (const char*)res, res_ld, (char*)out, out_ld, S, C, Cv)
   if (dtype == CTSEG_F32) CTSEG_FWD(float, 4);
+  else if (dtype == CTSEG_F16) { if (EPC_ == 8) CTSEG_FWD(F16, 8); else CTSEG_FWD(F16, 4); }
   else if (EPC_ == 8) CTSEG_FWD(BF16, 8);
   else CTSEG_FWD(BF16, 4);
 #undef CTSEG_FWD

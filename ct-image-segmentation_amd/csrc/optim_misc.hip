@@ -49,6 +49,11 @@ template <> __device__ __forceinline__ float cvt<float, float>(float x) { return
 template <> __device__ __forceinline__ unsigned short cvt<float, unsigned short>(float x) { return (unsigned short)f2bf(x); }
 template <> __device__ __forceinline__ float cvt<unsigned short, float>(unsigned short x) { return bf2f(x); }
 template <> __device__ __forceinline__ unsigned short cvt<unsigned short, unsigned short>(unsigned short x) { return x; }
+// IEEE half storage (CTSEG_F16) travels as _Float16 here so that it is a distinct type from the raw-ushort bf16
+template <> __device__ __forceinline__ _Float16 cvt<float, _Float16>(float x) {
+  return __builtin_bit_cast(_Float16, (unsigned short)f2h<F16>(x));
+}
+template <> __device__ __forceinline__ float cvt<_Float16, float>(_Float16 x) { return (float)x; }
 
 template <typename TD> __global__ void gather_cast_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
                                                            TD* __restrict__ dst, int64_t n) {
@@ -206,9 +211,11 @@ extern "C" int ctseg_adam_step(float* p, const float* g, float* m, float* v, int
 }
 
 extern "C" int ctseg_gather_cast(const float* src, const int32_t* idx, void* dst, int32_t dtype, int64_t n, void* stream) {
-  CTSEG_REQUIRE(src && idx && dst && n > 0 && (dtype == CTSEG_F32 || dtype == CTSEG_BF16), "gather_cast: bad arguments");
+  CTSEG_REQUIRE(src && idx && dst && n > 0 && (dtype == CTSEG_F32 || is16(dtype)), "gather_cast: bad arguments");
   if (dtype == CTSEG_F32)
     hipLaunchKernelGGL(gather_cast_kernel<float>, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, src, idx, (float*)dst, n);
+  else if (dtype == CTSEG_F16)
+    hipLaunchKernelGGL(gather_cast_kernel<_Float16>, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, src, idx, (_Float16*)dst, n);
   else
     hipLaunchKernelGGL(gather_cast_kernel<unsigned short>, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, src, idx,
                        (unsigned short*)dst, n);
@@ -229,6 +236,10 @@ extern "C" int ctseg_cast(const void* src, int32_t sd, void* dst, int32_t dd, in
   else if (sd == CTSEG_BF16 && dd == CTSEG_BF16)
     hipLaunchKernelGGL((cast_kernel<unsigned short, unsigned short>), grid, blk, 0, st, (const unsigned short*)src,
                        (unsigned short*)dst, n);
+  else if (sd == CTSEG_F32 && dd == CTSEG_F16)
+    hipLaunchKernelGGL((cast_kernel<float, _Float16>), grid, blk, 0, st, (const float*)src, (_Float16*)dst, n);
+  else if (sd == CTSEG_F16 && dd == CTSEG_F32)
+    hipLaunchKernelGGL((cast_kernel<_Float16, float>), grid, blk, 0, st, (const _Float16*)src, (float*)dst, n);
   else CTSEG_REQUIRE(false, "cast: bad dtypes %d -> %d", sd, dd);
   CTSEG_LAUNCH_CHECK("cast");
   return 0;
@@ -239,6 +250,7 @@ extern "C" int ctseg_nc_to_cl(const float* src, void* dst, int32_t dtype, int32_
   CTSEG_REQUIRE(src && dst && N > 0 && C > 0 && S > 0 && ld >= C, "nc_to_cl: bad arguments");
   dim3 grid(nblocks(S * ld), N);
   if (dtype == CTSEG_F32) hipLaunchKernelGGL(nc_to_cl_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, C, S, ld);
+  else if (dtype == CTSEG_F16) hipLaunchKernelGGL(nc_to_cl_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, C, S, ld);
   else hipLaunchKernelGGL(nc_to_cl_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, C, S, ld);
   CTSEG_LAUNCH_CHECK("nc_to_cl");
   return 0;
@@ -249,6 +261,7 @@ extern "C" int ctseg_cl_to_nc(const void* src, int32_t dtype, float* dst, int32_
   CTSEG_REQUIRE(src && dst && N > 0 && C > 0 && S > 0 && ld >= C, "cl_to_nc: bad arguments");
   dim3 grid(nblocks(S * C), N);
   if (dtype == CTSEG_F32) hipLaunchKernelGGL(cl_to_nc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, C, S, ld);
+  else if (dtype == CTSEG_F16) hipLaunchKernelGGL(cl_to_nc_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, dst, C, S, ld);
   else hipLaunchKernelGGL(cl_to_nc_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src, dst, C, S, ld);
   CTSEG_LAUNCH_CHECK("cl_to_nc");
   return 0;
@@ -260,6 +273,9 @@ extern "C" int ctseg_window_gather(const float* vol, int32_t Cin, int32_t X, int
   dim3 grid(nblocks((int64_t)rx * ry * rz * ld));
   if (dtype == CTSEG_F32)
     hipLaunchKernelGGL(window_gather_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, vol, Cin, X, Y, Z, x0, y0, z0, rx, ry, rz, cval, (float*)dst, ld);
+  else if (dtype == CTSEG_F16)
+    hipLaunchKernelGGL(window_gather_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, vol, Cin, X, Y, Z, x0, y0, z0, rx, ry, rz, cval,
+                       (_Float16*)dst, ld);
   else
     hipLaunchKernelGGL(window_gather_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, vol, Cin, X, Y, Z, x0, y0, z0, rx, ry, rz, cval,
                        (unsigned short*)dst, ld);
@@ -276,6 +292,9 @@ extern "C" int ctseg_window_gather_batch(const float* vol, int32_t Cin, int32_t 
   if (dtype == CTSEG_F32)
     hipLaunchKernelGGL(window_gather_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, vol, Cin, X, Y, Z, starts, rx, ry, rz,
                        cval, (float*)dst, ld);
+  else if (dtype == CTSEG_F16)
+    hipLaunchKernelGGL(window_gather_batch_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, vol, Cin, X, Y, Z, starts, rx,
+                       ry, rz, cval, (_Float16*)dst, ld);
   else
     hipLaunchKernelGGL(window_gather_batch_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, vol, Cin, X, Y, Z, starts, rx,
                        ry, rz, cval, (unsigned short*)dst, ld);

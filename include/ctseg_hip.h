@@ -9,7 +9,7 @@
  *
  * Layout convention: activations are channels-last, [N][X][Y][Z][ld] with `ld` >= C elements per
  * voxel (X,Y,Z are the reference's (H,W,D) after ToTensorV3, capstone/volumetric/transforms.py:40;
- * 2-D tensors use Z = 1).  dtype: CTSEG_F32 or CTSEG_BF16 storage, fp32 accumulation always.
+ * 2-D tensors use Z = 1).  dtype: CTSEG_F32, CTSEG_BF16 or (forward passes) CTSEG_F16 storage, fp32 accumulation always.
  *
  * Return value: 0 on success, negative on a rejected argument or a HIP launch error
  * (ctseg_last_error() gives the text).  Nothing here allocates, frees or synchronises.
@@ -28,6 +28,9 @@ extern "C" {
 #define CTSEG_BF16 1
 #define CTSEG_I16 2 /* raw-input dtypes of ctseg_resize3d_to_hwd only */
 #define CTSEG_U8 3
+#define CTSEG_F16 4 /* IEEE half storage, fp32 accumulation: the FORWARD (inference) passes only — ctseg_conv_igemm,
+                       ctseg_instnorm_prelu_fwd, ctseg_gather_cast, ctseg_nc_to_cl / cl_to_nc, ctseg_window_gather*;
+                       the backward passes and the loss gradient reject it (train in CTSEG_BF16 or CTSEG_F32) */
 #define CTSEG_MAX_TAPS 27
 #define CTSEG_MAX_CLASSES 8
 

@@ -68,6 +68,9 @@ def run_conv_module(mod, x, gy, dt, device):
         gxa = layer.emit_dgrad(ga)
         plan.run()
         gx = from_cl(gxa, dims == 2)
+    if dt == nat.F16:           # IEEE half storage: forward / input-gradient passes only (no weight-gradient kernels)
+        torch.cuda.synchronize()
+        return from_cl(y, dims == 2), gx, None, None
     layer.emit_wgrad(xa, ga)
     plan.run()
     torch.cuda.synchronize()

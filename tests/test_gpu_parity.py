@@ -367,7 +367,8 @@ def test_autograd_drop_in_path_equals_native_step(golden):
         np.testing.assert_allclose(wa[real], wn[real], rtol=0, atol=2e-5, err_msg=k)
         np.testing.assert_allclose(wa, wn, rtol=0, atol=2.1e-3, err_msg=k)
         checked += _assert_adam_moved_like_fixture(wn, w0, g[f"b_w1:{k}"], g[f"b_g:{k}"], k)
-        assert np.abs(wa - w0).max() > 0.5e-3, k                    # and a step was taken at all
+        if real.any():
+            assert np.abs(wa - w0)[real].max() > 0.5e-3, k          # and a step was taken at all
     assert checked > 0.5 * sum(p.numel() for p in m1.parameters())
     # second forward after the torch optimizer changed the weights in place: packed operands must refresh
     l1b = m1.training_step(batch, 1).item()

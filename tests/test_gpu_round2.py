@@ -162,76 +162,121 @@ def test_full_size_fp32_step_vs_oracle():
     pred = m.unet.engine().last_plan._ctseg_loss.predictions(eng.last_plan.logits.ptr(), eng.last_plan.logits.ld).cpu().long()
     opred = squash_predictions(ologits).reshape(1, -1)
     flips = int((pred != opred).sum())
-    cos = []
-    for (k, p), q in zip(om.named_parameters(), m.parameters()):
-        a, b = eng.store.grad_view(q).cpu().flatten().double(), p.grad.flatten().double()
-        if b.norm() > 1e-4:
-            cos.append((float(torch.dot(a, b) / (a.norm() * b.norm())), k))
+    # gradients: fp32 CPU and fp32 GPU sum up to 12.6 M terms per element in different orders, so where they disagree an fp64 run
+    # of the same oracle arbitrates: the GPU gradient must be as close to the fp64 one as the CPU fp32 gradient is (or within 1e-4)
+    import copy
+    om64 = copy.deepcopy(om).double()
+    om64.zero_grad()
+    _, _, _, _, l64 = om64.shared_step((batch[0].double(), batch[1], batch[2].double()), True)
+    l64.backward()
+    rows = []
+    for (k, p), (_, p64), q in zip(om.named_parameters(), om64.named_parameters(), m.parameters()):
+        g64 = p64.grad.flatten()
+        noise_only = k.endswith(".bias") and "residual" not in k and not k.endswith("model.2.1.conv.unit0.conv.bias")
+        if g64.norm() < 1e-4 or noise_only:        # a conv bias feeding an InstanceNorm has an analytically zero gradient
+            continue
+        e_gpu = float((eng.store.grad_view(q).cpu().flatten().double() - g64).norm() / g64.norm())
+        e_cpu = float((p.grad.flatten().double() - g64).norm() / g64.norm())
+        rows.append((e_gpu, e_cpu, k))
+    worst = sorted(rows, reverse=True)[:6]
     _dump("full_size_fp32_vs_oracle.json", {"logits_max_abs_err": err, "loss": loss.item(), "oracle_loss": oloss.item(),
-                                            "dice": dice, "oracle_dice": odice, "safe_fraction": float(safe.float().mean()),
-                                            "mask_flips_total": flips, "voxels": int(opred.numel()), "min_grad_cos": min(cos)})
+                                            "oracle_loss_fp64": float(l64), "dice": dice, "oracle_dice": odice,
+                                            "safe_fraction": float(safe.float().mean()), "mask_flips_total": flips,
+                                            "voxels": int(opred.numel()),
+                                            "worst_grad_rel_err_vs_fp64 (gpu, cpu_fp32, tensor)": worst})
     assert err < 1e-3, err
     assert abs(loss.item() - oloss.item()) < 1e-4 * abs(oloss.item())
     assert abs(dice - odice) <= 0.002
     assert float(safe.float().mean()) > 0.99
     assert torch.equal(pred.reshape(-1)[safe.reshape(-1)], opred.reshape(-1)[safe.reshape(-1)])
     assert flips <= 50, flips                      # near-ties below the logit error may flip; O(10) per volume expected
-    assert min(cos)[0] > 0.9999, min(cos)
+    for e_gpu, e_cpu, k in rows:
+        assert e_gpu <= max(1e-4, 2.0 * e_cpu), (k, e_gpu, e_cpu)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
 # (d) K-step trajectories
 # ----------------------------------------------------------------------------------------------------------------------
 K_STEPS = 12
+K_LEARN = 40
 
 
-def _oracle_curve(filters, batch, lr):
+def _oracle_curve(filters, batch, lr, loss_fx, steps):
     import oracle.trainer as OT
     torch.manual_seed(12342)
-    om = OT.OracleUNet3D(filters=filters, loss_fx=("CrossEntropy",), lr=lr)
+    om = OT.OracleUNet3D(filters=filters, loss_fx=loss_fx, lr=lr)
     sd = {k: v.clone() for k, v in om.state_dict().items()}
     opt = om.configure_optimizers()
     losses, dices = [], []
-    for _ in range(K_STEPS):
+    for _ in range(steps):
         losses.append(float(om.fit_step(batch, opt)))
         dices.append(float(om.logged["Mean Dice Score (train)"]))
     return sd, losses, dices
+
+
+def _learnable_batch(H, W, D):
+    """a task the network picks up within a few dozen steps, so the Dice curve actually climbs: nine large blocks (3 x 3 grid in
+    the H-W plane, ~30 % foreground) whose class shows in the image as an intensity offset under unit noise"""
+    g = torch.Generator().manual_seed(12342)
+    images = torch.randn(1, 1, H, W, D, generator=g)
+    masks = torch.zeros(1, 9, H, W, D, dtype=torch.uint8)
+    bh, bw = H // 4, W // 4
+    for c in range(9):
+        i, j = divmod(c, 3)
+        x0, y0 = H // 16 + i * (H // 3), W // 16 + j * (W // 3)
+        masks[0, c, x0:x0 + bh, y0:y0 + bw, D // 6:D - D // 6] = 1
+        images[0, 0, x0:x0 + bh, y0:y0 + bw, D // 6:D - D // 6] += 0.6 * (c + 1) * (1 if c % 2 else -1)
+    return images, masks, torch.ones(1, 9)
 
 
 @pytest.fixture(scope="module")
 def trajectory_oracle():
     from bench import synthetic_batch
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    out = {}
     batch = synthetic_batch(1, 128, 128, 32, "cpu", 12342)
-    return batch, _oracle_curve((32, 64, 128, 256), batch, 1e-3)
+    out["configs1"] = (batch, ("CrossEntropy",), _oracle_curve((32, 64, 128, 256), batch, 1e-3, ("CrossEntropy",), K_STEPS))
+    batch = _learnable_batch(64, 64, 32)
+    out["learnable"] = (batch, ("CrossEntropy", "Dice"), _oracle_curve((32, 64, 128, 256), batch, 1e-3, ("CrossEntropy", "Dice"), K_LEARN))
+    return out
+
+
+# (max |dDice|, max relative loss difference) each run must stay within at EVERY step.  fp32: north_star's Dice +-0.002.
+# bf16: what it measurably meets against the same fp32 oracle curve — configs1: 1.9e-4 / 2.7e-4 (as tight as fp32); learnable:
+# 0.0078 / 1.7 % while the Dice climbs 0.05 -> 0.99 at up to 0.06 per step (a fraction of a step of lag), and +-0.0002 once
+# converged (fp32 on the same curve: 0.0014 / 0.15 %).  Every run must also END within +-0.002 (mean of the last 5 steps).
+TRAJ_TOL = {("configs1", "fp32"): (0.002, 5e-3), ("configs1", "bf16"): (0.002, 5e-3),
+            ("learnable", "fp32"): (0.002, 5e-3), ("learnable", "bf16"): (0.012, 2.5e-2)}
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_k_step_trajectory_tracks_the_oracle(trajectory_oracle, precision):
-    """BASELINE.json configs[1] (the real network on 1x1x128x128x32), K optimizer steps from the same weights on the same batch:
-    per-step CrossEntropy and mean Dice against the oracle's curve.  fp32 must stay within north_star's Dice +-0.002 (and 0.5 %
-    of the loss) at EVERY step; bf16 is measured against the same curve with the tolerance it meets written here."""
+@pytest.mark.parametrize("task", ["configs1", "learnable"])
+def test_k_step_trajectory_tracks_the_oracle(trajectory_oracle, task, precision):
+    """K optimizer steps from the same weights on the same batch, per-step loss and mean Dice against the oracle's curve.
+    configs1: BASELINE.json configs[1] (the real network on 1x1x128x128x32 synthetic CT, 1.3 % foreground, CrossEntropy — Dice stays
+    near 0 there, as it does for the reference on such data).  learnable: the same network on a 64x64x32 task whose Dice climbs
+    (CrossEntropy + Dice loss), so "+-0.002" is a statement about a moving curve."""
     from capstone_amd.volumetric.base_trainer import BaseUNet3D
-    batch, (sd, olosses, odices) = trajectory_oracle
-    m = BaseUNet3D(filters=[32, 64, 128, 256], loss_fx=["CrossEntropy"], precision=precision, lr=1e-3)
+    batch, loss_fx, (sd, olosses, odices) = trajectory_oracle[task]
+    m = BaseUNet3D(filters=[32, 64, 128, 256], loss_fx=list(loss_fx), precision=precision, lr=1e-3)
     m.load_state_dict(sd)
     m.to(DEV)
     gb = tuple(t.to(DEV) for t in batch)
     losses, dices = [], []
-    for _ in range(K_STEPS):
+    for _ in range(len(olosses)):
         losses.append(float(m.fit_step(gb)))
         dices.append(float(m.logged["Mean Dice Score (train)"]))
     dl = [abs(a - b) / abs(b) for a, b in zip(losses, olosses)]
     dd = [abs(a - b) for a, b in zip(dices, odices)]
-    _dump(f"trajectory_{precision}.json", {"steps": K_STEPS, "loss": losses, "oracle_loss": olosses, "dice": dices,
-                                           "oracle_dice": odices, "max_rel_loss_diff": max(dl), "max_abs_dice_diff": max(dd)})
+    _dump(f"trajectory_{task}_{precision}.json", {"steps": len(olosses), "loss": losses, "oracle_loss": olosses, "dice": dices,
+                                                  "oracle_dice": odices, "max_rel_loss_diff": max(dl), "max_abs_dice_diff": max(dd)})
     assert olosses[-1] < 0.8 * olosses[0], "the curve must actually descend"
-    if precision == "fp32":
-        assert max(dd) <= 0.002, dd
-        assert max(dl) <= 5e-3, dl
-    else:
-        assert max(dd) <= 0.01, dd
-        assert max(dl) <= 3e-2, dl
+    if task == "learnable":
+        assert max(odices) > 0.2, "the Dice curve must actually climb"
+    tol_d, tol_l = TRAJ_TOL[(task, precision)]
+    assert max(dd) <= tol_d, dd
+    assert max(dl) <= tol_l, dl
+    assert abs(np.mean(dices[-5:]) - np.mean(odices[-5:])) <= 0.002
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -261,11 +306,19 @@ def test_optimizer_update_reaches_every_cached_plan_on_gpu(precision):
         om.fit_step(batch, opt)
     with torch.no_grad():
         yb1 = m(xb.to(DEV)).clone().cpu()
-    ref = om(xb).detach()
-    moved = float((ref - yb0).abs().max())
-    tol = 2e-3 if precision == "fp32" else 0.15
-    assert moved > 4 * tol, moved
-    assert float((yb1 - ref).abs().max()) < tol * max(1.0, float(ref.abs().max())), float((yb1 - ref).abs().max())
+    # exact check: a FRESH module holding the updated weights (its plan B is packed from them by construction) must produce the
+    # same bits — a stale plan B would still show the initial weights' output
+    torch.cuda.synchronize()
+    m3 = BaseUNet3D(filters=[8, 16, 32], loss_fx=["CrossEntropy"], lr=0.02, precision=precision)
+    m3.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    m3.to(DEV)
+    with torch.no_grad():
+        yb3 = m3(xb.to(DEV)).clone().cpu()
+    assert float((yb1 - yb0).abs().max()) > 0.05, "the update must be visible in plan B's output"
+    assert torch.equal(yb1, yb3)
+    if precision == "fp32":       # and against the oracle stepping alongside
+        ref = om(xb).detach()
+        assert float((yb1 - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max())), float((yb1 - ref).abs().max())
 
 
 def test_native_adam_state_checkpoint_round_trip_on_gpu():
@@ -287,3 +340,84 @@ def test_native_adam_state_checkpoint_round_trip_on_gpu():
     assert l1 == l2
     torch.cuda.synchronize()
     assert torch.equal(m1.unet.engine().store.flat_p, m2.unet.engine().store.flat_p)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fp16 storage (BASELINE.json configs[4]): every forward kernel family, op level, against torch CPU
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,cin,cout,shape,family", [
+    ("conv", 8, 12, (1, 9, 11, 7), "generic 256x16 tile"),
+    ("conv", 16, 24, (2, 6, 10, 5), "generic 256x32 tile"),
+    ("conv_s2", 8, 64, (1, 10, 12, 8), "generic 128x64 tile, stride 2"),
+    ("conv", 256, 256, (1, 8, 8, 6), "ring 192x256"),
+    ("conv", 128, 128, (2, 8, 8, 6), "ring 192x128"),
+    ("convT", 384, 64, (1, 5, 6, 4), "8-class generic + ring input gradient"),
+    ("conv", 32, 32, (2, 12, 16, 24), "LDS halo 64-byte voxels"),
+    ("conv", 16, 10, (1, 8, 8, 8), "LDS halo 32-byte voxels, 10 columns"),
+    ("conv", 64, 64, (1, 9, 20, 13), "streamed-weight halo"),
+    ("convT", 128, 32, (1, 8, 16, 16), "streamed-weight halo, 8 classes"),
+    ("convT", 64, 10, (1, 8, 8, 8), "up halo"),
+    ("conv_s2", 32, 128, (1, 18, 40, 24), "stride-2 halo"),
+    ("conv_s2", 1, 32, (1, 16, 16, 8), "stem"),
+    ("conv1", 128, 256, (1, 6, 6, 4), "1x1x1 residual"),
+])
+def test_fp16_forward_and_input_gradient_passes_vs_torch_cpu(kind, cin, cout, shape, family):
+    """IEEE-half storage (v_mfma_f32_16x16x32_f16, fp32 accumulate): the forward and input-gradient passes of every kernel family
+    the inference plans use.  Half keeps 11 significant bits: relative L-inf error < 4e-3 (bf16's bound in this file's
+    siblings is 2.5e-2)."""
+    from capstone_amd import _native as nat
+    from helpers import rel_err, run_conv_module
+    torch.manual_seed(cin + 3 * cout + shape[2])
+    if kind == "convT":
+        mod = torch.nn.ConvTranspose3d(cin, cout, 3, 2, 1, output_padding=1)
+    elif kind == "conv1":
+        mod = torch.nn.Conv3d(cin, cout, 1, 1, 0)
+    else:
+        mod = torch.nn.Conv3d(cin, cout, 3, 2 if kind == "conv_s2" else 1, 1)
+    x = torch.randn(shape[0], cin, *shape[1:])
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yy, gx, gw, gb = run_conv_module(mod, x, gy, nat.F16, DEV)
+    assert gw is None and gb is None
+    assert rel_err(yy, y.detach()) < 4e-3, family + ": forward"
+    if gx is not None:
+        assert rel_err(gx, xr.grad) < 4e-3, family + ": input gradient"
+
+
+def test_fp16_instnorm_prelu_and_saturating_store():
+    """InstanceNorm + PReLU forward in half storage (statistics from the fp32 accumulators of the conv epilogue), and the
+    saturating half store: a conv output beyond +-65504 is stored as +-65504, not inf (its statistics stay exact in fp32)."""
+    from capstone_amd import _native as nat
+    from capstone_amd.engine import GemmLayer
+    from capstone_amd.plan import _NormAct
+    from helpers import MiniPlan, from_cl, rel_err, to_cl
+    torch.manual_seed(1)
+    C = 16
+    x = torch.randn(2, C, 6, 10, 8)
+    x[0, 3] *= 50.0
+    conv = torch.nn.Conv3d(C, C, 1)
+    alpha = torch.nn.Parameter(torch.tensor([0.2]))
+    with torch.no_grad():
+        conv.weight.copy_(torch.eye(C).reshape(C, C, 1, 1, 1))
+        conv.bias.zero_()
+    plan = MiniPlan([conv.weight, conv.bias, alpha], DEV, nat.F16, 3)
+    layer = GemmLayer(plan, "id", False, 1, 1, C, [(conv.weight, conv.bias, C)], C)
+    plan.packer.finalize()
+    xa = to_cl(x, nat.F16, DEV)
+    y, stats = layer.emit_fwd(xa, want_stats=True)
+    out = _NormAct(plan, alpha).emit_fwd(y, stats, 0, None, None)
+    plan.run()
+    xin = xa.valid().float().cpu()
+    ref = torch.nn.functional.prelu(torch.nn.functional.instance_norm(xin), alpha.detach().cpu())
+    assert rel_err(from_cl(out), ref) < 2e-3
+    # saturation: weights of 1000 on inputs of ~100 -> |y| up to 1e5 > 65504
+    with torch.no_grad():
+        conv.weight.mul_(1000.0)
+    xb = to_cl(torch.full((1, C, 4, 4, 4), 100.0), nat.F16, DEV)
+    yb, _ = layer.emit_fwd(xb)
+    plan.run()
+    torch.cuda.synchronize()
+    v = yb.valid().float()
+    assert torch.isfinite(v).all() and float(v.max()) == 65504.0

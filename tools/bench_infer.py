@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--overlap", type=float, default=0.25)
     ap.add_argument("--mode", default="gaussian")
     ap.add_argument("--channels", type=int, nargs="+", default=[32, 64, 128, 256, 512])
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"])   # BASELINE.json configs[4]: fp16
     ap.add_argument("--iters", type=int, default=5)
     a = ap.parse_args()
     torch.manual_seed(12342)
