@@ -184,6 +184,12 @@ bool conv_halo_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_halo_tiles(const ConvKArgs& a);
 int conv_halo_slots(const ConvKArgs& a, int dtype);   // InstanceNorm partial slots per sample (= workgroups)
 void launch_conv_halo(ConvKArgs& a, int dtype, hipStream_t st);
+// conv_halo_x.hip: the same passes in 16-bit storage with 16-byte-chunked rows: LDS-DMA staging, x-column fragment reuse,
+// weights in registers (taken first where eligible)
+bool conv_halo_x_eligible(const ConvKArgs& a, int dtype, int nclass);
+bool conv_halo_x_stats_ok(const ConvKArgs& a);
+int conv_halo_x_slots(const ConvKArgs& a);
+void launch_conv_halo_x(ConvKArgs& a, hipStream_t st);
 // 8-class stride-2 "up" pass with <= 16 output channels (conv_up_halo.hip): one input tile for all parity classes
 bool conv_up_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_up_tiles(const ConvKArgs& a);

@@ -356,6 +356,7 @@ template <int VB, int NT> static int halo_grid(int total) {
 
 // workgroups (= InstanceNorm partial slots per sample) a launch with this geometry uses
 int conv_halo_slots(const ConvKArgs& a, int dtype) {
+  if (conv_halo_x_eligible(a, dtype, 1)) return conv_halo_x_slots(a);
   const int vb = a.Cg * (dtype == CTSEG_F32 ? 4 : 2), total = conv_halo_tiles(a) * a.N;
   if (vb == 64) return a.Cn > 16 ? halo_grid<64, 2>(total) : halo_grid<64, 1>(total);
   return a.Cn > 16 ? halo_grid<32, 2>(total) : halo_grid<32, 1>(total);
@@ -377,6 +378,7 @@ template <typename T, int VB, int NT> static void launch_halo(ConvKArgs& a, hipS
 }
 
 void launch_conv_halo(ConvKArgs& a, int dtype, hipStream_t st) {
+  if (conv_halo_x_eligible(a, dtype, 1)) { launch_conv_halo_x(a, st); return; }
   const int SZ = dtype == CTSEG_F32 ? 4 : 2;
   const int vb = a.Cg * SZ;
   const bool n2 = a.Cn > 16;

@@ -1,0 +1,542 @@
+// x-column LDS-halo kernel (gfx950): the 3x3x3 stride-1 passes with few channels in 16-bit storage — 32->32 at
+// 256x256x24, the 10->10 logits convolution at 512x512x48 and their input gradients (reference: the MONAI UNet built at
+// capstone/volumetric/base_trainer.py:65-72, levels 0 / top).
+//
+// Same LDS halo image, MFMA operand layout and epilogue contract as conv_halo.hip, whose phase ablation
+// (profiles/r02_halo_kernel_phase_ablation.txt) showed the time going to ~1700 bookkeeping instructions per tile and wave
+// around 56 MFMAs, with no overlap between staging, multiplies and stores.  What is different here:
+//
+//  * staging is LDS-DMA (buffer_load_dwordx4 ... lds): a wave-instruction fills 64 consecutive 16-byte slots of one channel-chunk
+//    plane; the per-lane source offset is a per-thread constant and a halo voxel outside the volume is ONE v_and + v_cmp +
+//    v_cndmask (one-hot coordinate bits of the lane against the tile's valid-coordinate mask) selecting an offset past the
+//    buffer range, for which the hardware delivers zeros.  No VGPR round trip, no ds_write pass, no branches;
+//  * a wave owns an x-COLUMN of the tile: the four 2x8 (y,z) patches at x0..x0+3 of one y pair.  The operand fragment of
+//    patch x for tap (dx,dy,dz) IS the fragment of patch x+dx for tap (0,dy,dz), so per (dy,dz) the wave reads the six
+//    fragments x0-1..x0+4 once and feeds twelve MFMAs from them: 0.5 ds_read_b128 per MFMA instead of 1.0-1.25;
+//  * the packed weights of the wave's 16 output columns stay in registers for the whole launch (27 or 15 fragments): nothing
+//    but the halo lives in LDS, so the 32-byte-voxel variant still fits three workgroups per CU;
+//  * every LDS read offset is an instruction immediate (the tap order is one of two canonical ones, checked on the host);
+//    stores are buffer stores with a per-thread constant offset, a scalar tile base and out-of-range offsets for the voxels a
+//    ragged tile does not own.
+#include "conv_common.h"
+
+#ifndef X_ABL
+#define X_ABL 0      // timing-only ablation builds (tools/ablate_halo_x.sh): 1 = no MFMAs, 2 = no stores, 4 = no DMA; results are garbage
+#endif
+
+namespace ctseg {
+
+constexpr int X_TX = 4, X_TY = 8, X_TZ = 8;
+constexpr int X_HX = X_TX + 2, X_HY = X_TY + 2, X_HZ = X_TZ + 2, X_HV = X_HX * X_HY * X_HZ;   // 600 halo voxels
+constexpr int X_PIECES = (X_HV + 63) / 64;                                                     // 10 DMA pieces per plane
+// plane stride in 16-byte slots: >= 64 * X_PIECES (a DMA piece writes 64 slots) and = 8 (mod 16), so that the two planes an
+// MFMA operand read combines in one 16-lane LDS group fall on disjoint halves of the 256-byte bank row (conv_halo.hip header)
+constexpr int X_HVP = 648;
+constexpr int X_PLANE = X_HVP * 16;
+constexpr int X_XSTRIDE = X_HY * X_HZ * 16;   // bytes between x planes of the halo
+
+typedef int32_t xi32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t __attribute__((address_space(3)))* x_lds_u32_ptr;
+__device__ void x_raw_buffer_load_lds(xi32x4 rsrc, x_lds_u32_ptr lds, int size, int voffset, int soffset, int offset,
+                                      int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+
+__device__ __forceinline__ xi32x4 x_make_rsrc(const void* p, uint32_t bytes) {
+  struct __attribute__((packed)) { const void* ptr; uint32_t range; uint32_t config; } r{p, bytes, 0x00020000u};
+  xi32x4 v = __builtin_bit_cast(xi32x4, r);
+  v[0] = __builtin_amdgcn_readfirstlane(v[0]);
+  v[1] = __builtin_amdgcn_readfirstlane(v[1]);
+  v[2] = __builtin_amdgcn_readfirstlane(v[2]);
+  v[3] = __builtin_amdgcn_readfirstlane(v[3]);
+  return v;
+}
+
+// r16 -> (dy, z) inside a 2x8 patch (same permutation as conv_halo.hip: every ds_read_b128 lane group is conflict free)
+__device__ __forceinline__ void x_patch_voxel(int r16, int& dy, int& z) {
+  dy = (0xEF80u >> r16) & 1;
+  z = (int)((0x2104765437653210ull >> (4 * r16)) & 7ull);
+}
+
+template <int VB> struct XCfg {
+  static constexpr int NPL = VB / 16;                  // 16-byte channel chunks per voxel = LDS planes
+  static constexpr int HALO = NPL * X_PLANE;           // one halo buffer
+  static constexpr int TYPES = VB == 64 ? 9 : 5;       // K steps per dx: one (dy,dz) tap of 32 channels, or a pair of taps of 16
+  static constexpr int NPIECE = NPL * X_PIECES;        // DMA pieces per tile
+};
+
+struct XGeom {
+  int tiles, tyn, tzn;        // tiles per sample, tiles along y / z
+  int in_sample_bytes;        // < 2^31 (host-checked)
+  int out_sample_bytes;
+  int add_sample_bytes;
+};
+
+// ADD: 0 none, 1 the addend is the INPUT tensor (identity residual: taken from the centre voxel of the LDS halo), 2 a tensor in
+// global memory (bf16/half like the input, or fp32 when P.add_f32).
+// A wave owns the x-column of one y pair for NT 16-column blocks of the output; NS such wave groups (4 waves each) split the
+// column blocks of a wider output between them.  Measured on 32 -> 32 at 2 x 256 x 256 x 24 (ms per launch, register-staged kernel
+// 0.22): NT = 1, NS = 2 with the weights in registers 0.165 (220-246 VGPRs: the operand reads sit right in front of their MFMAs);
+// NT = 2, NS = 1 (one wave per SIMD) with the weights in registers 0.257 (216 weight registers leave ONE operand quad: MFMA A/B
+// operands come from the 256 architectural VGPRs) and with the weights in LDS 0.22 (a lone wave per SIMD exposes every LDS wait the
+// scheduler leaves); NT = 1, NS = 2 with the weights in LDS is the configuration launched.
+template <typename H, int VB, int NT, int NS, bool FLIP, bool STATS, int ADD, bool OF32>
+__global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P, const XGeom G, int total_tiles) {
+  using CF = XCfg<VB>;
+  // WL: the packed weights live in LDS in FRAGMENT order (1 KB per (column block, dx, K-step group): lane l reads its 16 bytes at
+  // l * 16, conflict free by construction) instead of in registers: 54 fragments = 216 registers per lane do not fit beside the
+  // operand prefetch (MFMA A/B operands come from the 256 architectural VGPRs)
+  constexpr bool WL = NT * NS * 3 * CF::TYPES > 16;
+  constexpr int NTA = NT * NS;                           // column blocks of the workgroup
+  constexpr int WBYTES = WL ? NTA * 3 * CF::TYPES * 1024 : 0;
+  constexpr int NPL = CF::NPL, TYPES = CF::TYPES, NW = 4 * NS, NTHR = 64 * NW;
+  constexpr int NWD = CF::NPIECE % NW == 0 ? NW : 4;    // waves that issue DMA pieces (20 pieces over 8 waves: the first four)
+  constexpr int PPW = CF::NPIECE / NWD;                 // DMA pieces per such wave
+  static_assert(CF::NPIECE % NWD == 0, "every DMA wave issues the same number of pieces (counted vmcnt)");
+  constexpr int OSZ = OF32 ? 4 : 2;
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4];   // + per-wave statistics slots
+  char* const sW = smem + 2 * CF::HALO;
+  float* const sStats = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int yp = wave & 3, ns = wave >> 2;               // y pair of the column, wave group
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const ctseg_conv_class& K = P.cls[0];
+  const int col0 = blockIdx.y * (16 * NTA) + ns * 16 * NT;   // first output column of this wave
+  int pdy, pz;
+  x_patch_voxel(r16, pdy, pz);
+
+  // ---- weights -> registers, canonical order W[column block][dx + 1][type] whatever the pass (FLIP: the input-gradient pass
+  //      lists its taps with every offset negated, so its group of dx = -1 is the LAST nine taps and type t holds -(canonical)) ----
+  u32x4 W[WL ? 1 : NT][WL ? 1 : 3][WL ? 1 : TYPES];
+#pragma unroll
+  for (int j = 0; j < (WL ? NTA : NT); ++j) {
+    const int cb = WL ? blockIdx.y * (16 * NTA) + j * 16 : col0 + j * 16;
+    const char* wrow = P.w + (K.w_off + (int64_t)(cb + r16) * K.kpad) * 2;
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi)
+#pragma unroll
+      for (int t = 0; t < TYPES; ++t) {
+        const int fi = (j * 3 + dxi) * TYPES + t;       // fragment index
+        if (WL && (fi % NW) != wave) continue;          // each wave stages its share of the fragments
+        const int g = FLIP ? 2 - dxi : dxi;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if constexpr (VB == 64) {
+          const int tt = FLIP ? 8 - t : t;              // canonical (dy,dz) index t -> position inside the group
+          v = *reinterpret_cast<const u32x4*>(wrow + ((9 * g + tt) * 32 + q4 * 8) * 2);
+        } else {
+          const int tc = 2 * t + (q4 >> 1);             // canonical (dy,dz) index of this lane's half of the K step
+          if (tc < 9) {
+            const int tt = FLIP ? 8 - tc : tc;
+            v = *reinterpret_cast<const u32x4*>(wrow + ((9 * g + tt) * 16 + (q4 & 1) * 8) * 2);
+          }
+        }
+        if constexpr (WL) *reinterpret_cast<u32x4*>(sW + fi * 1024 + lane * 16) = v;
+        else W[j][dxi][t] = v;
+      }
+  }
+
+  // ---- per-lane constants -------------------------------------------------------------------------------------------------
+  // LDS read address of the fragment (plane h = 0, canonical type 0 = (dy,dz) = (-1,-1)): the rest are immediates
+  int rbase[VB == 64 ? 1 : TYPES];
+  {
+    const int vox = ((2 * yp + pdy + 1) * X_HZ + (pz + 1)) * 16;
+    if constexpr (VB == 64) {
+      rbase[0] = q4 * X_PLANE + vox;
+    } else {
+#pragma unroll
+      for (int t = 0; t < TYPES; ++t) {
+        const int tc = 2 * t + (q4 >> 1);
+        const int tcc = tc < 9 ? tc : 4;                // the empty half of the last K step reads the centre tap (weights are 0)
+        rbase[t] = (q4 & 1) * X_PLANE + vox + ((tcc / 3 - 1) * X_HZ + (tcc % 3 - 1)) * 16;
+      }
+    }
+  }
+  // DMA pieces of this wave: source byte offset from the halo origin voxel and one-hot coordinate bits
+  int poff[PPW];
+  uint32_t phot[PPW];
+  const int YZ = P.Yi * P.Zi;
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int piece = (wave % NWD) + j * NWD;
+    const int pl = piece / X_PIECES, hv = (piece % X_PIECES) * 64 + lane;
+    const int hx = hv / (X_HY * X_HZ), rem = hv - hx * (X_HY * X_HZ);
+    const int hy = rem / X_HZ, hz = rem - hy * X_HZ;
+    poff[j] = ((hx * YZ + hy * P.Zi + hz) * P.g_ld + pl * 8) * 2;
+    phot[j] = hv < X_HV ? ((1u << hx) | (1u << (6 + hy)) | (1u << (16 + hz))) : 0x80000000u;
+  }
+  const int bias_bytes = (YZ + P.Zi + 1) * P.g_ld * 2;    // the halo origin of a tile at x0 = y0 = z0 = 0 lies this far before the sample
+  // output: per-lane byte offset of (plane 0, this lane's voxel, its 4 channels of column block 0) from the tile's first voxel
+  const int chn = col0 + 4 * q4;
+  bool ch_ok[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) ch_ok[j] = chn + 16 * j < P.Cn_store;
+  const int ooff = ((2 * yp + pdy) * P.Zo + pz) * P.o_ld * OSZ + chn * OSZ;
+  const int oplane = P.Yo * P.Zo * P.o_ld * OSZ;
+  const int ASZ = P.add_f32 ? 4 : 2;
+  const int aoff = ADD == 2 ? ((2 * yp + pdy) * P.Zo + pz) * P.add_ld * ASZ + chn * ASZ : 0;
+  const int aplane = ADD == 2 ? P.Yo * P.Zo * P.add_ld * ASZ : 0;
+  // centre voxel of the halo for the identity-residual addend: the lane's 4 channels inside their 16-byte chunk (column block j: + 2 planes)
+  const int cbase = ADD == 1 ? ((chn * 2) >> 4) * X_PLANE + ((1 * X_HY + (2 * yp + pdy + 1)) * X_HZ + (pz + 1)) * 16 + ((chn * 2) & 15) : 0;
+  float bias[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias[j][e] = (P.bias != nullptr && chn + 16 * j + e < P.Cn) ? P.bias[chn + 16 * j + e] : 0.f;
+
+  float wsum[NT][4], wsq[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { wsum[j][e] = 0.f; wsq[j][e] = 0.f; }
+  int stat_n = -1;
+  auto flush_stats = [&](int n) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = wsum[j][e], b = wsq[j][e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (r16 == 0) {
+          sStats[(wave * 2 + 0) * 16 * NT + j * 16 + 4 * q4 + e] = a;
+          sStats[(wave * 2 + 1) * 16 * NT + j * 16 + 4 * q4 + e] = b;
+        }
+        wsum[j][e] = 0.f;
+        wsq[j][e] = 0.f;
+      }
+    __syncthreads();
+    if (tid < 2 * 16 * NTA) {
+      const int which = tid / (16 * NTA), c = tid % (16 * NTA), grp = c / (16 * NT), cc = c % (16 * NT);
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) a += sStats[((grp * 4 + w) * 2 + which) * 16 * NT + cc];
+      const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + blockIdx.x;
+      P.stats[(slot_t * 2 + which) * P.stats_ld + blockIdx.y * (16 * NTA) + c] = a;
+    }
+    __syncthreads();
+  };
+
+  struct Org { int n, x0, y0, z0; };
+  auto tile_origin = [&](int t) -> Org {
+    Org o;
+    o.n = t / G.tiles;
+    int r = t - o.n * G.tiles;
+    const int tz = r % G.tzn; r /= G.tzn;
+    const int ty = r % G.tyn; const int tx = r / G.tyn;
+    o.x0 = tx * X_TX; o.y0 = ty * X_TY; o.z0 = tz * X_TZ;
+    return o;
+  };
+  auto range_mask = [](int lo, int hi, int nbits) -> uint32_t {   // bits lo..hi (clamped to 0..nbits-1)
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > nbits - 1 ? nbits - 1 : hi;
+    return hi < lo ? 0u : ((2u << hi) - (1u << lo));
+  };
+  auto dma = [&](const Org& o, int buf) {
+    // halo coordinate h of an axis is voxel x0 - 1 + h: inside the volume for h in [1 - x0, Xi - x0]
+    const uint32_t m = range_mask(1 - o.x0, P.Xi - o.x0, X_HX) | (range_mask(1 - o.y0, P.Yi - o.y0, X_HY) << 6) |
+                       (range_mask(1 - o.z0, P.Zi - o.z0, X_HZ) << 16);
+    const uint32_t notm = ~m;
+    const xi32x4 rs = x_make_rsrc(P.in + (int64_t)o.n * G.in_sample_bytes - bias_bytes, (uint32_t)(G.in_sample_bytes + bias_bytes));
+    const int soff = ((o.x0 * P.Yi + o.y0) * P.Zi + o.z0) * P.g_ld * 2;    // halo origin = tile origin - (1,1,1) = this + (rsrc base shift)
+    char* dst = smem + buf * CF::HALO;
+    if (NWD < NW && wave >= NWD) return;
+    if (X_ABL & 4) return;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int piece = wave + j * NWD;
+      const int vo = (phot[j] & notm) == 0u ? poff[j] : (int)0x80000000;
+      x_raw_buffer_load_lds(rs, (x_lds_u32_ptr)(dst + (piece / X_PIECES) * X_PLANE + (piece % X_PIECES) * 1024), 16, vo, soff, 0, 0);
+    }
+  };
+
+  // ---- epilogue of one tile, in a head (per-tile scalars, addend loads) and X_TX slices (one x plane each) so that the slices
+  //      can be issued between the K steps of the NEXT tile's multiplies ---------------------------------------------------------
+  struct Ep {
+    int nx, sbase;
+    bool lane_ok;
+    __amdgpu_buffer_rsrc_t ors;
+    u32x4 gadd[NT][X_TX];
+  };
+  auto ep_head = [&](const Org& o, Ep& e) {
+    if (STATS && o.n != stat_n) {
+      if (stat_n >= 0) flush_stats(stat_n);
+      stat_n = o.n;
+    }
+    e.nx = P.Xr - o.x0;                                          // planes of the tile inside the row grid (may exceed X_TX)
+    e.lane_ok = (o.y0 + 2 * yp + pdy < P.Yr) && (o.z0 + pz < P.Zr);
+    const int64_t tvox = ((int64_t)o.x0 * P.Yo + o.y0) * P.Zo + o.z0;
+    e.sbase = (int)(tvox * P.o_ld * OSZ);                        // < 2^31 (host-checked per sample)
+    e.ors = __builtin_amdgcn_make_buffer_rsrc(P.out + (int64_t)o.n * G.out_sample_bytes, 0, G.out_sample_bytes, 0x00020000);
+    if constexpr (ADD == 2) {
+      const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.add) + (int64_t)o.n * G.add_sample_bytes, 0,
+                                                                            G.add_sample_bytes, 0x00020000);
+      const int abase = (int)(tvox * P.add_ld * ASZ);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < X_TX; ++i) {
+          const int vo = (e.lane_ok && ch_ok[j] && i < e.nx) ? aoff + 16 * j * ASZ : (int)0x80000000;
+          if (P.add_f32) e.gadd[j][i] = __builtin_amdgcn_raw_buffer_load_b128(ars, vo, abase + i * aplane, 0);
+          else {
+            const u32x2 w2 = __builtin_amdgcn_raw_buffer_load_b64(ars, vo, abase + i * aplane, 0);
+            e.gadd[j][i] = u32x4{w2[0], w2[1], 0u, 0u};
+          }
+        }
+    }
+  };
+  auto ep_slice = [&](const Ep& e, const f32x4 (&acc)[NT][X_TX], const u32x2 (&cadd)[NT][X_TX], int i) {
+    const bool ok = e.lane_ok && i < e.nx;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = acc[j][i][q] + bias[j][q];
+        if (STATS) {
+          const float sv = ok ? v[q] : 0.f;
+          wsum[j][q] += sv;
+          wsq[j][q] += sv * sv;
+        }
+      }
+      if constexpr (ADD == 1) {
+        v[0] += h2f<H>(cadd[j][i][0] & 0xffffu); v[1] += h2f<H>(cadd[j][i][0] >> 16);
+        v[2] += h2f<H>(cadd[j][i][1] & 0xffffu); v[3] += h2f<H>(cadd[j][i][1] >> 16);
+      } else if constexpr (ADD == 2) {
+        if (P.add_f32) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += __uint_as_float(e.gadd[j][i][q]);
+        } else {
+          v[0] += h2f<H>(e.gadd[j][i][0] & 0xffffu); v[1] += h2f<H>(e.gadd[j][i][0] >> 16);
+          v[2] += h2f<H>(e.gadd[j][i][1] & 0xffffu); v[3] += h2f<H>(e.gadd[j][i][1] >> 16);
+        }
+      }
+      const int vo = (ok && ch_ok[j] && !(X_ABL & 2)) ? ooff + 16 * j * OSZ : (int)0x80000000;
+      if constexpr (OF32) {
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                               e.ors, vo, e.sbase + i * oplane, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])}, e.ors, vo, e.sbase + i * oplane, 0);
+      }
+    }
+  };
+
+  // multiplies of one tile from halo[buf] into `acc`; with PREV the epilogue slices of the previous tile (accumulators `pacc`)
+  // are spread over the K steps: their conversions, statistics and stores issue under this tile's MFMAs
+  auto compute_tile = [&](auto prev_c, int buf, f32x4 (&acc)[NT][X_TX], u32x2 (&cadd)[NT][X_TX], const Ep& pe,
+                          const f32x4 (&pacc)[NT][X_TX], const u32x2 (&pcadd)[NT][X_TX]) {
+    constexpr bool PREV = decltype(prev_c)::value;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < X_TX; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* hb = smem + buf * CF::HALO;
+    auto frag_base = [&](int t) -> const char* {
+      if constexpr (VB == 64) return hb + rbase[0] + ((t / 3) * X_HZ + (t % 3)) * 16 - (X_HZ + 1) * 16;
+      else return hb + rbase[t];
+    };
+    // the fragments of K-step group t+1 (operand + LDS-resident weights) are requested before the multiplies of group t: one
+    // group of LDS latency is always covered by 12 * NT MFMAs
+    u32x4 F[2][X_HX], Wb[2][WL ? NT : 1][WL ? 3 : 1];
+    auto load_group = [&](int t, u32x4 (&f)[X_HX], u32x4 (&w)[WL ? NT : 1][WL ? 3 : 1]) {
+#pragma unroll
+      for (int h = 0; h < X_HX; ++h) f[h] = *reinterpret_cast<const u32x4*>(frag_base(t) + h * X_XSTRIDE);
+      if constexpr (WL) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int dxi = 0; dxi < 3; ++dxi)
+            w[j][dxi] = *reinterpret_cast<const u32x4*>(sW + (((ns * NT + j) * 3 + dxi) * TYPES + t) * 1024 + lane * 16);
+      }
+    };
+    load_group(0, F[0], Wb[0]);
+#pragma unroll
+    for (int t = 0; t < TYPES; ++t) {
+      if (t + 1 < TYPES) load_group(t + 1, F[(t + 1) & 1], Wb[(t + 1) & 1]);
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < X_TX; ++i) {
+            if constexpr ((X_ABL & 1) != 0) {      // keep the operand reads alive without the matrix pipe
+              acc[j][i][0] += __uint_as_float((WL ? Wb[t & 1][j][dxi][1] : W[WL ? 0 : j][WL ? 0 : dxi][WL ? 0 : t][1]) ^ F[t & 1][i + dxi][0]);
+              continue;
+            }
+            if constexpr (WL) mma16<H>(acc[j][i], Wb[t & 1][j][dxi], F[t & 1][i + dxi]);
+            else mma16<H>(acc[j][i], W[j][dxi][t], F[t & 1][i + dxi]);
+          }
+      if constexpr (PREV) {
+        constexpr int every = TYPES >= 2 * X_TX ? 2 : 1;          // 9 K-step groups: slices after groups 0,2,4,6; 5 groups: after 0..3
+        if (t % every == 0 && t / every < X_TX) ep_slice(pe, pacc, pcadd, t / every);
+      }
+    }
+    if constexpr (ADD == 1) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < X_TX; ++i) cadd[j][i] = *reinterpret_cast<const u32x2*>(hb + cbase + 2 * j * X_PLANE + i * X_XSTRIDE);
+    }
+  };
+
+  // ---- tile sequence of this workgroup (as conv_halo.hip: each XCD owns a contiguous range, walked round-robin) -----------------
+  const int Gd = gridDim.x;
+  int first, stride, last;
+  if ((Gd & 7) == 0) {
+    const int chunk = (total_tiles + 7) / 8, xcd = blockIdx.x & 7;
+    first = xcd * chunk + (blockIdx.x >> 3);
+    stride = Gd >> 3;
+    last = (xcd + 1) * chunk < total_tiles ? (xcd + 1) * chunk : total_tiles;
+  } else {
+    first = blockIdx.x; stride = Gd; last = total_tiles;
+  }
+  // Per tile t: [wait for this wave's DMA pieces of tile t] [barrier: halo[buf] complete, everyone done with halo[buf^1]]
+  // [DMA of tile t+1 into halo[buf^1]] [multiplies of tile t from halo[buf], with the epilogue of tile t-1 between its K steps].
+  // The X_TX stores of that epilogue are the only vector-memory operations younger than the DMA, so the counted wait at the top
+  // of the next tile (all but the X_TX youngest) covers exactly the DMA pieces; before the first epilogue it is a full wait.
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  if (first >= last) return;
+  f32x4 accA[NT][X_TX], accB[NT][X_TX];
+  u32x2 caddA[NT][X_TX], caddB[NT][X_TX];
+  Ep ep;
+  Org ocur = tile_origin(first);
+  dma(ocur, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // DMA pieces landed; the weight fragments this wave staged are written
+  __builtin_amdgcn_s_barrier();
+  Org onext = ocur;
+  int t = first;
+  if (t + stride < last) { onext = tile_origin(t + stride); dma(onext, 1); }
+  compute_tile(F_{}, 0, accA, caddA, ep, accA, caddA);
+  // invariant at the loop head: set A holds the finished multiplies of tile t (origin ocur); tile t+stride (origin onext) is in
+  // flight into halo[1]
+  constexpr int NSTORE = X_TX * NT;      // vector-memory operations of one tile's epilogue
+  auto advance = [&](int buf, f32x4 (&cur)[NT][X_TX], u32x2 (&ccur)[NT][X_TX], f32x4 (&prv)[NT][X_TX], u32x2 (&cprv)[NT][X_TX], bool counted) {
+    // tile t+stride becomes the current one: its multiplies go to `cur` while the epilogue of tile t runs from `prv`
+    if (ADD == 2 || !counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const Org odone = ocur;
+    ocur = onext;
+    t += stride;
+    if (t + stride < last) { onext = tile_origin(t + stride); dma(onext, buf ^ 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    ep_head(odone, ep);
+    compute_tile(T_{}, buf, cur, ccur, ep, prv, cprv);
+  };
+  bool counted = false;
+  while (true) {
+    if (t + stride >= last) { ep_head(ocur, ep);
+#pragma unroll
+      for (int i = 0; i < X_TX; ++i) ep_slice(ep, accA, caddA, i);
+      break; }
+    advance(1, accB, caddB, accA, caddA, counted);
+    counted = true;
+    if (t + stride >= last) { ep_head(ocur, ep);
+#pragma unroll
+      for (int i = 0; i < X_TX; ++i) ep_slice(ep, accB, caddB, i);
+      break; }
+    advance(0, accA, caddA, accB, caddB, counted);
+  }
+  if (STATS && stat_n >= 0) flush_stats(stat_n);
+}
+
+// -------------------------------------------------------------------------------------------------------------------------------------
+static int x_tap_order(const ConvKArgs& a) {   // 0: canonical (offset = t - 1 per axis, x slowest), 1: every offset negated, -1: neither
+  int kind = -1;
+  for (int flip = 0; flip < 2 && kind < 0; ++flip) {
+    bool ok = true;
+    for (int j = 0; j < 27 && ok; ++j) {
+      const int tp = a.cls[0].taps[j];
+      const int s = flip ? -1 : 1;
+      const int ex = s * (j / 9 - 1), ey = s * ((j / 3) % 3 - 1), ez = s * (j % 3 - 1);
+      ok = (int)(int8_t)(tp & 0xff) == ex && (int)(int8_t)((tp >> 8) & 0xff) == ey && (int)(int8_t)((tp >> 16) & 0xff) == ez;
+    }
+    if (ok) kind = flip;
+  }
+  return kind;
+}
+
+bool conv_halo_x_eligible(const ConvKArgs& a, int dtype, int nclass) {
+  if (getenv("CTSEG_NO_HALO_X") != nullptr) return false;
+  if (!is16(dtype) || nclass != 1 || a.cls[0].ntaps != 27 || a.sin != 1 || a.sout != 1) return false;
+  const int vb = a.Cg * 2;
+  if (!(vb == 32 || vb == 64) || a.Cn > 32) return false;
+  if ((a.g_ld * 2) % 16 != 0 || ((uintptr_t)a.in % 16) != 0) return false;      // 12-wide rows stay on the register-staged kernel
+  if (a.Xr != a.Xi || a.Yr != a.Yi || a.Zr != a.Zi || a.Zr < 4) return false;
+  const int64_t YZ = (int64_t)a.Yi * a.Zi;
+  if (((int64_t)a.Xi * YZ + YZ + a.Zi + 1) * a.g_ld * 2 >= (1ll << 31) - 65536) return false;
+  const int64_t osz = a.out_f32 ? 4 : 2;
+  if ((int64_t)a.Xo * a.Yo * a.Zo * a.o_ld * osz >= (1ll << 31) - 65536) return false;
+  if (a.add != nullptr && (int64_t)a.Xo * a.Yo * a.Zo * a.add_ld * (a.add_f32 ? 4 : 2) >= (1ll << 31) - 65536) return false;
+  if (a.out2 != nullptr) return false;
+  if (a.cls[0].kpad < 27 * a.Cg) return false;
+  const int order = x_tap_order(a);
+  if (order < 0) return false;
+  if (a.out_f32 && order == 1) return false;        // fp32 output exists for the forward tap order only (the logits)
+  return true;                                      // (independent of a.stats: sizing queries run before the partial buffer exists)
+}
+
+// InstanceNorm partials exist for the forward tap order with 16-bit output and no addend (what the plans record)
+bool conv_halo_x_stats_ok(const ConvKArgs& a) { return x_tap_order(a) == 0 && !a.out_f32 && a.add == nullptr;
+}
+
+static int x_tiles(const ConvKArgs& a) { return ((a.Xr + X_TX - 1) / X_TX) * ((a.Yr + X_TY - 1) / X_TY) * ((a.Zr + X_TZ - 1) / X_TZ); }
+
+static int x_grid(const ConvKArgs& a) {
+  const int vb = a.Cg * 2, total = x_tiles(a) * a.N;
+  // LDS: 2 x 41.5 KB of halo (+ 27 / 54 KB of weight fragments) per workgroup at 64-byte voxels: one workgroup per CU;
+  // 2 x 20.7 KB at 32-byte voxels with the 15 weight fragments of 16 columns in registers: two per CU
+  const int per_cu = (vb == 64 || a.Cn > 16) ? 1 : 2;
+  const int gx = 256 * per_cu;
+  return gx > total ? total : gx;
+}
+
+int conv_halo_x_slots(const ConvKArgs& a) { return x_grid(a); }
+
+template <typename H, int VB, int NT, int NS, bool FLIP>
+static void x_launch(ConvKArgs& a, const XGeom& g, int total, dim3 grid, hipStream_t st) {
+  const bool stats = a.stats != nullptr, of32 = a.out_f32 != 0;
+  // identity residual: the addend is the input tensor itself, every stored channel is present in the staged voxel
+  const bool addc = a.add == a.in && a.add_ld == a.g_ld && a.add_f32 == 0 && a.Cn_store * 2 <= VB && grid.y == 1;
+  const int add = a.add == nullptr ? 0 : (addc ? 1 : 2);
+  const dim3 blk(256 * NS);
+#define X_GO(ST, AD, OF) hipLaunchKernelGGL((conv_halo_x_kernel<H, VB, NT, NS, FLIP, ST, AD, OF>), grid, blk, 0, st, a, g, total)
+  if constexpr (!FLIP) {     // forward passes: InstanceNorm partials (16-bit output, no addend) or the fp32 logits
+    if (stats) { X_GO(true, 0, false); return; }
+    if (of32) {
+      if (add == 1) X_GO(false, 1, true); else if (add == 2) X_GO(false, 2, true); else X_GO(false, 0, true);
+      return;
+    }
+  }
+  if (add == 1) X_GO(false, 1, false); else if (add == 2) X_GO(false, 2, false); else X_GO(false, 0, false);
+#undef X_GO
+}
+
+void launch_conv_halo_x(ConvKArgs& a, hipStream_t st) {
+  XGeom g;
+  g.tyn = (a.Yr + X_TY - 1) / X_TY; g.tzn = (a.Zr + X_TZ - 1) / X_TZ;
+  g.tiles = x_tiles(a);
+  a.tiles = g.tiles;
+  g.in_sample_bytes = (int)((int64_t)a.Xi * a.Yi * a.Zi * a.g_ld * 2);
+  g.out_sample_bytes = (int)((int64_t)a.Xo * a.Yo * a.Zo * a.o_ld * (a.out_f32 ? 4 : 2));
+  g.add_sample_bytes = a.add ? (int)((int64_t)a.Xo * a.Yo * a.Zo * a.add_ld * (a.add_f32 ? 4 : 2)) : 0;
+  const int total = g.tiles * a.N;
+  const int vb = a.Cg * 2, nt = a.Cn > 16 ? 2 : 1;
+  const dim3 grid((unsigned)x_grid(a), 1u, 1u);
+  const bool flip = x_tap_order(a) == 1;
+#define X_DT(H)                                                                                                         \
+  do {                                                                                                                  \
+    if (vb == 64) {                                                                                                     \
+      if (nt == 2) { if (flip) x_launch<H, 64, 1, 2, true>(a, g, total, grid, st); else x_launch<H, 64, 1, 2, false>(a, g, total, grid, st); } \
+      else { if (flip) x_launch<H, 64, 1, 1, true>(a, g, total, grid, st); else x_launch<H, 64, 1, 1, false>(a, g, total, grid, st); }         \
+    } else {                                                                                                            \
+      if (nt == 2) { if (flip) x_launch<H, 32, 1, 2, true>(a, g, total, grid, st); else x_launch<H, 32, 1, 2, false>(a, g, total, grid, st); } \
+      else { if (flip) x_launch<H, 32, 1, 1, true>(a, g, total, grid, st); else x_launch<H, 32, 1, 1, false>(a, g, total, grid, st); }         \
+    }                                                                                                                   \
+  } while (0)
+  if (a.dtype == CTSEG_F16) X_DT(F16); else X_DT(BF16);
+#undef X_DT
+}
+
+}  // namespace ctseg

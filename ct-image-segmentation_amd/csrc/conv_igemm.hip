@@ -376,6 +376,9 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   a.out2 = (char*)d->out2; a.out2_col0 = d->out2_col0; a.o2_ld = d->o2_ld; a.xcd_order = 0;
   a.dtype = d->dtype;
   const bool halo = conv_halo_eligible(a, d->dtype, d->nclass);
+  if (halo && d->stats && conv_halo_x_eligible(a, d->dtype, d->nclass))
+    CTSEG_REQUIRE(conv_halo_x_stats_ok(a), "conv_igemm: InstanceNorm partials with an addend / fp32 output / input-gradient taps "
+                                           "are not implemented on the x-column halo pass");
   const bool up = !halo && conv_up_eligible(a, d->dtype, d->nclass);
   const bool stem = !halo && !up && conv_stem_eligible(a, d->dtype, d->nclass);
   const bool sw = !halo && !up && !stem && conv_halo_sw_eligible(a, d->dtype, d->nclass);
@@ -422,6 +425,10 @@ static void fill_args(const ctseg_conv_desc* d, ConvKArgs& a) {
   a.w = (const char*)d->w; a.Cn_store = d->Cn_store;
   a.in = (const char*)d->in; a.N = d->N; a.Xi = d->Xi; a.Yi = d->Yi; a.Zi = d->Zi; a.Xr = d->Xr; a.Yr = d->Yr; a.Zr = d->Zr;
   a.Cg = d->Cg; a.Cn = d->Cn; a.g_ld = d->g_ld; a.sin = d->sin; a.sout = d->sout; a.rows = d->Xr * d->Yr * d->Zr;
+  // everything a kernel-selection predicate may look at (the same answer at sizing time and at launch time)
+  a.out = (char*)d->out; a.add = (const char*)d->add; a.bias = d->bias; a.stats = nullptr;
+  a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo; a.o_ld = d->o_ld; a.add_ld = d->add_ld; a.out_f32 = d->out_f32; a.add_f32 = d->add_f32;
+  a.tiles = 0; a.stats_ld = 0; a.stats_tiles = 0; a.stats_tile0 = 0; a.o2_ld = 0;
   for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
 }
 

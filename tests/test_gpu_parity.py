@@ -611,6 +611,9 @@ def test_narrow_rows_change_no_forward_bit_and_no_gradient_beyond_sum_order(monk
     touches them can move such rows.  The layout changes no arithmetic of the forward pass (logits bit-identical to the
     16-wide plan); the backward differs only in the order of the fp32 InstanceNorm-backward partial sums."""
     from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    # both layouts on the SAME kernels: 16-byte-chunked rows would otherwise take the x-column halo kernel (conv_halo_x.hip), whose
+    # K order differs from the register-staged kernel the 12-wide rows run on (equal up to fp32 summation order, tested below)
+    monkeypatch.setenv("CTSEG_NO_HALO_X", "1")
     g = torch.Generator().manual_seed(21)
     images = torch.randn(2, 1, 32, 48, 16, generator=g).to(DEV)
     masks = (torch.rand(2, 9, 32, 48, 16, generator=g) < 0.1).to(torch.uint8).to(DEV)
@@ -630,6 +633,35 @@ def test_narrow_rows_change_no_forward_bit_and_no_gradient_beyond_sum_order(monk
     assert torch.equal(out["1"][1], out["0"][1])
     ga, gb = out["1"][2], out["0"][2]
     assert float((ga - gb).abs().max()) <= 2e-3 * float(gb.abs().max())
+
+
+def test_x_column_halo_kernel_equals_register_staged_kernel_up_to_sum_order(monkeypatch):
+    """conv_halo_x.hip (LDS-DMA staging, x-column fragment reuse, weights in registers) against conv_halo.hip on a whole training
+    step in the 16-wide layout: same operands, same fp32 accumulators, only the order of the K steps differs."""
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    monkeypatch.setenv("CTSEG_NARROW_ROWS", "0")
+    g = torch.Generator().manual_seed(23)
+    images = torch.randn(2, 1, 32, 48, 16, generator=g).to(DEV)
+    masks = (torch.rand(2, 9, 32, 48, 16, generator=g) < 0.1).to(torch.uint8).to(DEV)
+    ind = torch.ones(2, 9, dtype=torch.float64).to(DEV)
+    out = {}
+    for off in ("0", "1"):
+        if off == "1":
+            monkeypatch.setenv("CTSEG_NO_HALO_X", "1")
+        else:
+            monkeypatch.delenv("CTSEG_NO_HALO_X", raising=False)
+        torch.manual_seed(5)
+        m = BaseUNet3D(filters=[32, 64, 128], loss_fx=["CrossEntropy"], precision="bf16").to(DEV)
+        loss = float(m.fit_step((images, masks, ind)))
+        eng = m.unet.engine()
+        torch.cuda.synchronize()
+        out[off] = (loss, eng.logits_view().clone(), eng.store.flat_g.clone())
+    assert abs(out["0"][0] - out["1"][0]) <= 1e-4 * abs(out["1"][0])
+    la, lb = out["0"][1], out["1"][1]
+    assert float((la - lb).abs().max()) <= 2e-2 * float(lb.abs().max())      # bf16 re-rounding of activations downstream
+    ga, gb = out["0"][2], out["1"][2]
+    cos = float(torch.dot(ga.double(), gb.double()) / (ga.double().norm() * gb.double().norm()))
+    assert cos > 0.9995, cos
 
 
 def test_narrow_rows_fall_back_where_a_pass_cannot_move_them(monkeypatch):
