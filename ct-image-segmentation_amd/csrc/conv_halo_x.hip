@@ -78,8 +78,12 @@ struct XGeom {
 // NT = 2, NS = 1 (one wave per SIMD) with the weights in registers 0.257 (216 weight registers leave ONE operand quad: MFMA A/B
 // operands come from the 256 architectural VGPRs) and with the weights in LDS 0.22 (a lone wave per SIMD exposes every LDS wait the
 // scheduler leaves); NT = 1, NS = 2 with the weights in LDS is the configuration launched.
-template <typename H, int VB, int NT, int NS, bool FLIP, bool STATS, int ADD, bool OF32>
+// R12: the gathered rows are 12 elements wide (24 bytes: the 10-class tensors of the head): such a row cannot be moved in 16-byte DMA
+// pieces, so the halo is staged through registers in 8-byte pieces (buffer loads with the same out-of-range trick, then
+// ds_write_b64 into the same two-plane LDS image; the upper half of every plane-1 slot is zeroed once and never written again).
+template <typename H, int VB, int NT, int NS, bool FLIP, bool STATS, int ADD, bool OF32, bool R12>
 __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P, const XGeom G, int total_tiles) {
+  static_assert(!R12 || (VB == 32 && NS == 1), "12-wide rows: 16 gathered channels, one wave group");
   using CF = XCfg<VB>;
   // WL: the packed weights live in LDS in FRAGMENT order (1 KB per (column block, dx, K-step group): lane l reads its 16 bytes at
   // l * 16, conflict free by construction) instead of in registers: 54 fragments = 216 registers per lane do not fit beside the
@@ -165,6 +169,23 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     poff[j] = ((hx * YZ + hy * P.Zi + hz) * P.g_ld + pl * 8) * 2;
     phot[j] = hv < X_HV ? ((1u << hx) | (1u << (6 + hy)) | (1u << (16 + hz))) : 0x80000000u;
   }
+  // R12 staging: 3 eight-byte pieces per halo voxel (bytes 0-7, 8-15 -> plane 0; 16-23 -> plane 1), voxel-major so that a wave's
+  // loads run along the 240-byte z rows of the volume
+  constexpr int R_N = X_HV * 3, R_J = R12 ? (R_N + NTHR - 1) / NTHR : 1;
+  int roff[R_J], rlds[R_J];
+  uint32_t rhot[R_J];
+  if constexpr (R12) {
+#pragma unroll
+    for (int j = 0; j < R_J; ++j) {
+      const int idx = tid + j * NTHR;
+      const int hv = idx / 3, part = idx - hv * 3;
+      const int hx = hv / (X_HY * X_HZ), rem = hv - hx * (X_HY * X_HZ);
+      const int hy = rem / X_HZ, hz = rem - hy * X_HZ;
+      roff[j] = (hx * YZ + hy * P.Zi + hz) * P.g_ld * 2 + part * 8;
+      rhot[j] = idx < R_N ? ((1u << hx) | (1u << (6 + hy)) | (1u << (16 + hz))) : 0x80000000u;
+      rlds[j] = (part == 2 ? X_PLANE : 0) + hv * 16 + (part == 1 ? 8 : 0);
+    }
+  }
   const int bias_bytes = (YZ + P.Zi + 1) * P.g_ld * 2;    // the halo origin of a tile at x0 = y0 = z0 = 0 lies this far before the sample
   // output: per-lane byte offset of (plane 0, this lane's voxel, its 4 channels of column block 0) from the tile's first voxel
   const int chn = col0 + 4 * q4;
@@ -248,6 +269,27 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
       const int vo = (phot[j] & notm) == 0u ? poff[j] : (int)0x80000000;
       x_raw_buffer_load_lds(rs, (x_lds_u32_ptr)(dst + (piece / X_PIECES) * X_PLANE + (piece % X_PIECES) * 1024), 16, vo, soff, 0, 0);
     }
+  };
+
+  u32x2 rg[R_J];
+  auto gload = [&](const Org& o) {
+    const uint32_t m = range_mask(1 - o.x0, P.Xi - o.x0, X_HX) | (range_mask(1 - o.y0, P.Yi - o.y0, X_HY) << 6) |
+                       (range_mask(1 - o.z0, P.Zi - o.z0, X_HZ) << 16);
+    const uint32_t notm = ~m;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.in) + (int64_t)o.n * G.in_sample_bytes - bias_bytes, 0,
+                                                                         G.in_sample_bytes + bias_bytes, 0x00020000);
+    const int soff = ((o.x0 * P.Yi + o.y0) * P.Zi + o.z0) * P.g_ld * 2;
+#pragma unroll
+    for (int j = 0; j < R_J; ++j) {
+      const int vo = (rhot[j] & notm) == 0u ? roff[j] : (int)0x80000000;
+      rg[j] = (X_ABL & 4) ? u32x2{0u, 0u} : __builtin_amdgcn_raw_buffer_load_b64(rs, vo, soff, 0);
+    }
+  };
+  auto sstore = [&](int buf) {
+    char* dst = smem + buf * CF::HALO;
+#pragma unroll
+    for (int j = 0; j < R_J; ++j)
+      if (R_J * NTHR == R_N || tid + j * NTHR < R_N) *reinterpret_cast<u32x2*>(dst + rlds[j]) = rg[j];
   };
 
   // ---- epilogue of one tile, in a head (per-tile scalars, addend loads) and X_TX slices (one x plane each) so that the slices
@@ -401,28 +443,51 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
   u32x2 caddA[NT][X_TX], caddB[NT][X_TX];
   Ep ep;
   Org ocur = tile_origin(first);
-  dma(ocur, 0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // DMA pieces landed; the weight fragments this wave staged are written
-  __builtin_amdgcn_s_barrier();
   Org onext = ocur;
   int t = first;
-  if (t + stride < last) { onext = tile_origin(t + stride); dma(onext, 1); }
-  compute_tile(F_{}, 0, accA, caddA, ep, accA, caddA);
+  if constexpr (R12) {
+    // zero the pad half (channels 12..15) of every plane-1 slot of both buffers once
+    for (int i = tid; i < 2 * X_HVP; i += NTHR)
+      *reinterpret_cast<u32x2*>(smem + (i / X_HVP) * CF::HALO + X_PLANE + (i % X_HVP) * 16 + 8) = u32x2{0u, 0u};
+    gload(ocur);
+    sstore(0);
+    __syncthreads();
+    if (t + stride < last) { onext = tile_origin(t + stride); gload(onext); }
+    compute_tile(F_{}, 0, accA, caddA, ep, accA, caddA);
+    if (t + stride < last) sstore(1);
+    __syncthreads();
+  } else {
+    dma(ocur, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // DMA pieces landed; the weight fragments this wave staged are written
+    __builtin_amdgcn_s_barrier();
+    if (t + stride < last) { onext = tile_origin(t + stride); dma(onext, 1); }
+    compute_tile(F_{}, 0, accA, caddA, ep, accA, caddA);
+  }
   // invariant at the loop head: set A holds the finished multiplies of tile t (origin ocur); tile t+stride (origin onext) is in
-  // flight into halo[1]
+  // flight into halo[1] (R12: already stored there, behind a barrier)
   constexpr int NSTORE = X_TX * NT;      // vector-memory operations of one tile's epilogue
   auto advance = [&](int buf, f32x4 (&cur)[NT][X_TX], u32x2 (&ccur)[NT][X_TX], f32x4 (&prv)[NT][X_TX], u32x2 (&cprv)[NT][X_TX], bool counted) {
     // tile t+stride becomes the current one: its multiplies go to `cur` while the epilogue of tile t runs from `prv`
-    if (ADD == 2 || !counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!R12) {
+      if (ADD == 2 || !counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     const Org odone = ocur;
     ocur = onext;
     t += stride;
-    if (t + stride < last) { onext = tile_origin(t + stride); dma(onext, buf ^ 1); }
+    const bool more = t + stride < last;
+    if (more) {
+      onext = tile_origin(t + stride);
+      if constexpr (R12) gload(onext); else dma(onext, buf ^ 1);
+    }
     __builtin_amdgcn_sched_barrier(0);
     ep_head(odone, ep);
     compute_tile(T_{}, buf, cur, ccur, ep, prv, cprv);
+    if constexpr (R12) {
+      if (more) sstore(buf ^ 1);     // halo[buf ^ 1] was last read by the multiplies of the previous tile, behind the last barrier
+      __syncthreads();
+    }
   };
   bool counted = false;
   while (true) {
@@ -462,7 +527,8 @@ bool conv_halo_x_eligible(const ConvKArgs& a, int dtype, int nclass) {
   if (!is16(dtype) || nclass != 1 || a.cls[0].ntaps != 27 || a.sin != 1 || a.sout != 1) return false;
   const int vb = a.Cg * 2;
   if (!(vb == 32 || vb == 64) || a.Cn > 32) return false;
-  if ((a.g_ld * 2) % 16 != 0 || ((uintptr_t)a.in % 16) != 0) return false;      // 12-wide rows stay on the register-staged kernel
+  // gathered rows: 16-byte chunked, or 12 elements wide (24 bytes) with 16 gathered channels and at most 16 columns
+  if (((a.g_ld * 2) % 16 != 0 && !(a.g_ld == 12 && vb == 32 && a.Cn <= 16)) || ((uintptr_t)a.in % 16) != 0) return false;
   if (a.Xr != a.Xi || a.Yr != a.Yi || a.Zr != a.Zi || a.Zr < 4) return false;
   const int64_t YZ = (int64_t)a.Yi * a.Zi;
   if (((int64_t)a.Xi * YZ + YZ + a.Zi + 1) * a.g_ld * 2 >= (1ll << 31) - 65536) return false;
@@ -501,7 +567,14 @@ static void x_launch(ConvKArgs& a, const XGeom& g, int total, dim3 grid, hipStre
   const bool addc = a.add == a.in && a.add_ld == a.g_ld && a.add_f32 == 0 && a.Cn_store * 2 <= VB && grid.y == 1;
   const int add = a.add == nullptr ? 0 : (addc ? 1 : 2);
   const dim3 blk(256 * NS);
-#define X_GO(ST, AD, OF) hipLaunchKernelGGL((conv_halo_x_kernel<H, VB, NT, NS, FLIP, ST, AD, OF>), grid, blk, 0, st, a, g, total)
+  const bool r12 = a.g_ld == 12;
+#define X_GO(ST, AD, OF)                                                                                                  \
+  do {                                                                                                                    \
+    if constexpr (VB == 32 && NS == 1) {                                                                                  \
+      if (r12) { hipLaunchKernelGGL((conv_halo_x_kernel<H, VB, NT, NS, FLIP, ST, AD, OF, true>), grid, blk, 0, st, a, g, total); break; } \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((conv_halo_x_kernel<H, VB, NT, NS, FLIP, ST, AD, OF, false>), grid, blk, 0, st, a, g, total);       \
+  } while (0)
   if constexpr (!FLIP) {     // forward passes: InstanceNorm partials (16-bit output, no addend) or the fp32 logits
     if (stats) { X_GO(true, 0, false); return; }
     if (of32) {
