@@ -98,6 +98,8 @@ _SIGS = {
     "ctseg_colsum": (C.c_int, [_i32, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp]),
     "ctseg_squash_masks": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "ctseg_seg_loss": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "ctseg_conv_logits_ce_slots": (C.c_int, [C.POINTER(ConvDesc), _i32]),
+    "ctseg_conv_logits_ce": (C.c_int, [C.POINTER(ConvDesc), _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ctseg_dice_counts": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     "ctseg_reduce_partials_f64": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "ctseg_loss_dice_summary": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),

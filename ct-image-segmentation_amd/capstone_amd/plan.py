@@ -398,8 +398,22 @@ class Plan:
             self.packer.refresh(force=True)
             self._repack_ev = side.record_event()
 
-    def forward(self, x=None):
-        """x = None: the caller already filled ``self.x`` (sliding-window gather writes it directly)"""
+    def head_ce_slots(self, n_classes):
+        """partial-sum slots per sample of ctseg_conv_logits_ce for this plan's logits convolution (0: not eligible — the
+        convolution and the loss then run as two passes)"""
+        cache = getattr(self, "_head_ce", None)
+        if cache is None or cache[0] != n_classes:
+            slots = 0
+            name, _, args = self.fwd[-1]
+            if (name == "ctseg_conv_igemm" and not self.inference and args[0].out == self.logits.ptr() and
+                    os.environ.get("CTSEG_FUSED_HEAD_CE", "1") != "0"):
+                slots = nat.lib().ctseg_conv_logits_ce_slots(args[0], n_classes)
+            cache = self._head_ce = (n_classes, max(slots, 0), args[0])
+        return cache[1]
+
+    def forward(self, x=None, skip_head=False):
+        """x = None: the caller already filled ``self.x`` (sliding-window gather writes it directly).  skip_head: stop before the
+        logits convolution (the caller runs it fused with the loss: ctseg_conv_logits_ce); ``self.logits`` is then NOT updated."""
         if x is not None:
             self.load_input(x)
         ev = getattr(self, "_repack_ev", None)
@@ -408,7 +422,8 @@ class Plan:
             self._repack_ev = None
         self.packer.refresh()
         self.fwd_gen += 1
-        self.run(self.fwd, nat.stream_ptr())
+        self.run(self.fwd, nat.stream_ptr(), 0, len(self.fwd) - 1 if skip_head else None)
+        self.logits_current = not skip_head
         return self.logits
 
     # weight-gradient work (split-K GEMM + slab reduce, transposed-conv bias sums) depends only on tensors that are final when

@@ -121,6 +121,19 @@ class SegLossEngine:
         nat.call("ctseg_reduce_partials_f64", self.part.data_ptr(), self.B, self.P, self.R,
                  (self.red_w if weighted else self.red).data_ptr())
 
+    def head_ce(self, desc, slots, dl_ptr, g_ld, weighted=False):
+        """the logits convolution and the cross-entropy (loss sums, Dice counts, d loss / d logits) in ONE launch: ``desc`` is the
+        recorded descriptor of the plan's last forward op, ``slots`` = plan.head_ce_slots().  Same tables as fused_ce."""
+        if getattr(self, "_ce_ready", None) is not weighted:
+            self.prepare_fused_ce(weighted)
+        self._ce_ready = None
+        part = getattr(self, "_part_head", None)
+        if part is None or part.shape[1] != slots:
+            part = self._part_head = torch.zeros((self.B, slots, self.R), dtype=torch.float64, device=self.device)
+        nat.call("ctseg_conv_logits_ce", desc, self.labels.data_ptr(), self.C, nat.ptr(self.cw if weighted else None),
+                 self.coef.data_ptr(), self.coef.shape[1], dl_ptr, g_ld, part.data_ptr(), slots, self.R, self.cnt.data_ptr())
+        nat.call("ctseg_reduce_partials_f64", part.data_ptr(), self.B, slots, self.R, (self.red_w if weighted else self.red).data_ptr())
+
     def ce_summary(self, weighted=False):
         """(loss, mean Dice, Dice per class) of the last fused_ce pass as views of one small tensor: one launch instead of the
         ~20 scalar-sized torch kernels of loss_values() + dice_metric()"""

@@ -170,7 +170,10 @@ class BaseUNet3D(_Base):
             self.log(f"Mean Dice Score ({prefix})", dice_mean, on_step=False, on_epoch=True)
 
     # ---- native step: what Lightning's loop does per batch, without autograd -------------------------
-    def fit_step(self, batch, betas=(0.9, 0.999), eps=1e-8):
+    def fit_step(self, batch, betas=(0.9, 0.999), eps=1e-8, keep_logits=True):
+        """keep_logits=False lets a cross-entropy-only step run the logits convolution with the loss fused into its epilogue
+        (ctseg_conv_logits_ce): the fp32 logits are then never materialised and ``engine.logits_view()`` is stale after the step;
+        loss, Dice metric, gradients and the update are the same (gradient of the loss w.r.t. the logits bit-identical)."""
         images, masks, mask_indicator = batch
         nat.require_gpu(images, "fit_step")
         eng = self.unet.engine()
@@ -181,6 +184,8 @@ class BaseUNet3D(_Base):
             le = plan._ctseg_loss = segloss.SegLossEngine(images.device, images.shape[0], plan.logits.S, self._n_classes)
         names = list(self.loss_func.names)
         ce_only = len(names) == 1 and names[0] in ("CrossEntropy", "WeightedCrossEntropy")
+        head_slots = plan.head_ce_slots(self._n_classes) if (ce_only and not keep_logits) else 0
+        fused_head = head_slots > 0
         if side is not None:
             # the label map is not needed before the loss: squash the masks (and build the loss tables that need only the label
             # histogram) on the side stream while the forward pass starts
@@ -193,15 +198,17 @@ class BaseUNet3D(_Base):
                     le.prepare_fused_ce(weighted=names[0] != "CrossEntropy")
             for t in (lab_u8, hist):
                 t.record_stream(main)
-            logits = plan.forward(images)
+            logits = plan.forward(images, skip_head=fused_head)
             main.wait_stream(side)
         else:
             lab_u8, _, hist = segloss.squash_masks(masks, self._n_classes, want_i64=False)
             le.set_labels(lab_u8, hist)
-            logits = plan.forward(images)
+            logits = plan.forward(images, skip_head=fused_head)
         dl = plan.dlogits
         vals = None
-        if ce_only:
+        if fused_head:
+            le.head_ce(plan._head_ce[2], head_slots, dl.ptr(), dl.ld, weighted=names[0] != "CrossEntropy")
+        elif ce_only:
             le.fused_ce(logits.ptr(), logits.ld, dl.ptr(), dl.ld, plan.dt, weighted=names[0] != "CrossEntropy")
         else:
             le.stats(logits.ptr(), logits.ld, weighted_too="WeightedCrossEntropy" in names)

@@ -70,6 +70,22 @@ struct XGeom {
   int add_sample_bytes;
 };
 
+// Cross-entropy fused into the epilogue of the logits convolution (CE = true): the fp32 logits never leave the registers.  What
+// ctseg_seg_loss's cross-entropy-only path computes per voxel (capstone/models/losses.py:45-68 F.cross_entropy [weighted],
+// training/utils.py:19-20 softmax -> argmax, models/metrics.py:15-21 Dice counts) is computed here with the same arithmetic.
+struct XCe {
+  const uint8_t* labels;            // [N][S]
+  const float* class_weight;        // [C] or NULL
+  const float* coef;                // per sample: coef[n * coef_stride] = d(loss)/d(weighted NLL sum) (1 / denominator)
+  int coef_stride;
+  char* dlogits;                    // [N][S][g_ld] 16-bit storage of the pass
+  int g_ld;
+  double* part;                     // [N][P][R]: entries 0 (weighted NLL sum) and 1 (weight sum) of slot blockIdx.x; the rest zeroed
+  int P, R;
+  unsigned long long* cnt;          // [N][3][C] += (|pred==c & true==c|, |pred==c|, |true==c|)
+  int C;
+};
+
 // ADD: 0 none, 1 the addend is the INPUT tensor (identity residual: taken from the centre voxel of the LDS halo), 2 a tensor in
 // global memory (bf16/half like the input, or fp32 when P.add_f32).
 // A wave owns the x-column of one y pair for NT 16-column blocks of the output; NS such wave groups (4 waves each) split the
@@ -81,9 +97,10 @@ struct XGeom {
 // R12: the gathered rows are 12 elements wide (24 bytes: the 10-class tensors of the head): such a row cannot be moved in 16-byte DMA
 // pieces, so the halo is staged through registers in 8-byte pieces (buffer loads with the same out-of-range trick, then
 // ds_write_b64 into the same two-plane LDS image; the upper half of every plane-1 slot is zeroed once and never written again).
-template <typename H, int VB, int NT, int NS, bool FLIP, bool STATS, int ADD, bool OF32, bool R12>
-__global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P, const XGeom G, int total_tiles) {
+template <typename H, int VB, int NT, int NS, bool FLIP, bool STATS, int ADD, bool OF32, bool R12, bool CE = false>
+__global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P, const XGeom G, int total_tiles, const XCe E) {
   static_assert(!R12 || (VB == 32 && NS == 1), "12-wide rows: 16 gathered channels, one wave group");
+  static_assert(!CE || (VB == 32 && NS == 1 && NT == 1 && !FLIP && !STATS && ADD != 2), "fused cross-entropy: the logits convolution");
   using CF = XCfg<VB>;
   // WL: the packed weights live in LDS in FRAGMENT order (1 KB per (column block, dx, K-step group): lane l reads its 16 bytes at
   // l * 16, conflict free by construction) instead of in registers: 54 fragments = 216 registers per lane do not fit beside the
@@ -97,9 +114,14 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
   static_assert(CF::NPIECE % NWD == 0, "every DMA wave issues the same number of pieces (counted vmcnt)");
   constexpr int OSZ = OF32 ? 4 : 2;
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4];   // + per-wave statistics slots
+  constexpr int CE_T = CE ? NW * X_TX * 16 * 48 : 0;        // per-wave transpose scratch: 12 fp32 logits per voxel
+  constexpr int CE_B = CE ? 3 * 16 * 4 + NW * 2 * 8 : 0;     // Dice counters, per-wave loss sums
+  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B];
   char* const sW = smem + 2 * CF::HALO;
-  float* const sStats = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES);
+  float* const sStats = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES);     // per-wave statistics slots
+  char* const sT = smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4;
+  unsigned int* const sCnt = reinterpret_cast<unsigned int*>(sT + CE_T);
+  double* const sSum = reinterpret_cast<double*>(sT + CE_T + 3 * 16 * 4);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -421,6 +443,137 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     }
   };
 
+  // ---- fused cross-entropy epilogue ------------------------------------------------------------------------------------------
+  float ce_nll = 0.f, ce_w = 0.f;
+  unsigned int u_cnt[3][12];              // wave-uniform Dice counters (|pred & true|, |pred|, |true| per class)
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int c = 0; c < 12; ++c) u_cnt[k][c] = 0u;
+  int ce_n = -1;
+  auto ce_flush = [&](int n) {            // this workgroup's record of sample n (slot blockIdx.x) and its Dice counts
+    const double a = wave_sum((double)ce_nll), b = wave_sum((double)ce_w);
+    if (lane == 0) { sSum[2 * wave] = a; sSum[2 * wave + 1] = b; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        if (lane == 0 && u_cnt[k][c] != 0u) atomicAdd(&sCnt[k * 16 + c], u_cnt[k][c]);
+        u_cnt[k][c] = 0u;
+      }
+    ce_nll = 0.f;
+    ce_w = 0.f;
+    __syncthreads();
+    if (tid < E.R) {
+      double v = 0.0;
+      if (tid < 2) v = sSum[tid] + sSum[2 + tid] + sSum[4 + tid] + sSum[6 + tid];
+      E.part[((int64_t)n * E.P + blockIdx.x) * E.R + tid] = v;
+    }
+    if (tid < 3 * E.C) {
+      const int k = tid / E.C, c = tid % E.C;
+      const unsigned int v = sCnt[k * 16 + c];
+      if (v) atomicAdd(&E.cnt[((int64_t)n * 3 + k) * E.C + c], (unsigned long long)v);
+    }
+    __syncthreads();
+    if (tid < 48) sCnt[tid] = 0u;
+    __syncthreads();
+  };
+  auto ce_epilogue = [&](const Org& o, f32x4 (&acc)[NT][X_TX], u32x2 (&cadd)[NT][X_TX]) {
+    if (o.n != ce_n) {
+      if (ce_n >= 0) ce_flush(ce_n);
+      ce_n = o.n;
+    }
+    // logits = conv + bias (+ identity residual), then a wave-local exchange through LDS: lane (r16, q4) ends up with the 12 values
+    // of voxel r16 of x plane q4 (it held channels 4 q4 .. 4 q4 + 3 of all four planes)
+    char* sc = sT + wave * (X_TX * 16 * 48);
+#pragma unroll
+    for (int i = 0; i < X_TX; ++i) {
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = acc[0][i][q] + bias[0][q];
+      if constexpr (ADD == 1) {
+        v[0] += h2f<H>(cadd[0][i][0] & 0xffffu); v[1] += h2f<H>(cadd[0][i][0] >> 16);
+        v[2] += h2f<H>(cadd[0][i][1] & 0xffffu); v[3] += h2f<H>(cadd[0][i][1] >> 16);
+      }
+      if (q4 < 3) *reinterpret_cast<f32x4*>(sc + (i * 16 + r16) * 48 + q4 * 16) = v;
+    }
+    float x[12];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sc + (q4 * 16 + r16) * 48 + q * 16);
+      x[4 * q] = v[0]; x[4 * q + 1] = v[1]; x[4 * q + 2] = v[2]; x[4 * q + 3] = v[3];
+    }
+    const int C = E.C;
+    const int xg = o.x0 + q4, yg = o.y0 + 2 * yp + pdy, zg = o.z0 + pz;
+    const bool valid = xg < P.Xr && yg < P.Yr && zg < P.Zr;
+    const int64_t vox = (((int64_t)o.n * P.Xo + xg) * P.Yo + yg) * P.Zo + zg;
+    const int t = valid ? (int)E.labels[vox] : 0;
+    // ---- per-voxel cross-entropy.  seg_loss_kernel (loss_metric.hip) spends ~350 VALU instructions per voxel on ten expf, ten IEEE
+    //      divisions and a logf; here that work is NOT hidden behind an HBM stream, so: exp through v_exp_f32, one reciprocal of the
+    //      sum instead of ten divisions.  The prediction keeps the reference's exact semantics (softmax in fp32, THEN argmax, first
+    //      maximal index, capstone/training/utils.py:19-20): the largest logit has e = exp(0) = 1 exactly, and another class can only
+    //      tie with it after the division if its e is within an ulp of 1 — lanes that hold such a near-tie (rare; wave-uniform test)
+    //      redo the softmax with expf and true divisions exactly as seg_loss_kernel does.
+    float m = x[0];
+#pragma unroll
+    for (int c = 1; c < 12; ++c) if (c < C) m = fmaxf(m, x[c]);
+    float e[12], ssum = 0.f;
+    int pred = -1, near = 0;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      e[c] = (c < C) ? __expf(x[c] - m) : 0.f;
+      if (c < C) {
+        ssum += e[c];
+        if (x[c] == m) { if (pred < 0) pred = c; }
+        if (x[c] - m > -1e-3f) ++near;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(near > 1) != 0ull) {
+      if (near > 1) {
+        float e2[12], s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 12; ++c) { e2[c] = (c < C) ? expf(x[c] - m) : 0.f; if (c < C) s2 += e2[c]; }
+        float best = -1.f;
+        pred = 0;
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+          const float p2 = (c < C) ? e2[c] / s2 : 0.f;
+          if (c < C && p2 > best) { best = p2; pred = c; }
+        }
+      }
+    }
+    const float rs = 1.f / ssum;
+    const float lse = m + logf(ssum);
+    float xt = 0.f;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) if (c == t) xt = x[c];
+    const float w = (E.class_weight != nullptr && t < C) ? E.class_weight[t] : 1.f;
+    if (valid) {
+      ce_nll += w * (lse - xt);
+      ce_w += w;
+    }
+    // Dice counts: wave-wide ballots per class (98 % of the voxels are background: per-voxel atomics on one counter would serialise)
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      if (c < C) {
+        const unsigned long long bt = __builtin_amdgcn_ballot_w64(valid && t == c), bp = __builtin_amdgcn_ballot_w64(valid && pred == c);
+        u_cnt[0][c] += (unsigned)__popcll(bt & bp);
+        u_cnt[1][c] += (unsigned)__popcll(bp);
+        u_cnt[2][c] += (unsigned)__popcll(bt);
+      }
+    }
+    const float ce_scale = E.coef[(int64_t)o.n * E.coef_stride] * w;
+    float d[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) d[c] = (c < C) ? ce_scale * (e[c] * rs - ((c == t) ? 1.f : 0.f)) : 0.f;
+    if (valid) {
+      char* gp = E.dlogits + vox * E.g_ld * 2;
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        *reinterpret_cast<u32x2*>(gp + u * 8) = u32x2{pack2<H>(d[4 * u], d[4 * u + 1]), pack2<H>(d[4 * u + 2], d[4 * u + 3])};
+    }
+  };
+
   // ---- tile sequence of this workgroup (as conv_halo.hip: each XCD owns a contiguous range, walked round-robin) -----------------
   const int Gd = gridDim.x;
   int first, stride, last;
@@ -438,13 +591,53 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
   // of the next tile (all but the X_TX youngest) covers exactly the DMA pieces; before the first epilogue it is a full wait.
   using T_ = std::true_type;
   using F_ = std::false_type;
-  if (first >= last) return;
+  if (first >= last) {
+    if constexpr (CE) {
+      for (int n = 0; n < P.N; ++n)
+        if (tid < E.R) E.part[((int64_t)n * E.P + blockIdx.x) * E.R + tid] = 0.0;
+    }
+    return;
+  }
   f32x4 accA[NT][X_TX], accB[NT][X_TX];
   u32x2 caddA[NT][X_TX], caddB[NT][X_TX];
   Ep ep;
   Org ocur = tile_origin(first);
   Org onext = ocur;
   int t = first;
+  if constexpr (CE) {
+    // not software-pipelined: the loss arithmetic needs the registers the second accumulator set would take, and two workgroups per
+    // CU overlap each other's phases
+    if (tid < 48) sCnt[tid] = 0u;
+    if constexpr (R12) {
+      for (int i = tid; i < 2 * X_HVP; i += NTHR)
+        *reinterpret_cast<u32x2*>(smem + (i / X_HVP) * CF::HALO + X_PLANE + (i % X_HVP) * 16 + 8) = u32x2{0u, 0u};
+      gload(ocur);
+      sstore(0);
+    } else {
+      dma(ocur, 0);
+    }
+    int buf = 0;
+    for (;; t += stride, buf ^= 1) {
+      const bool more = t + stride < last;
+      if constexpr (R12) __syncthreads();
+      else { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+      if (more) {
+        onext = tile_origin(t + stride);
+        if constexpr (R12) gload(onext); else dma(onext, buf ^ 1);
+      }
+      compute_tile(F_{}, buf, accA, caddA, ep, accA, caddA);
+      ce_epilogue(ocur, accA, caddA);
+      if constexpr (R12) { if (more) sstore(buf ^ 1); }
+      if (!more) break;
+      ocur = onext;
+    }
+    ce_flush(ce_n);
+    // samples this workgroup never touched: zero records (the host sums every slot of every sample)
+    const int n_first = first / G.tiles, n_last = (last - 1) / G.tiles;
+    for (int n = 0; n < P.N; ++n)
+      if ((n < n_first || n > n_last) && tid < E.R) E.part[((int64_t)n * E.P + blockIdx.x) * E.R + tid] = 0.0;
+    return;
+  }
   if constexpr (R12) {
     // zero the pad half (channels 12..15) of every plane-1 slot of both buffers once
     for (int i = tid; i < 2 * X_HVP; i += NTHR)
@@ -571,9 +764,9 @@ static void x_launch(ConvKArgs& a, const XGeom& g, int total, dim3 grid, hipStre
 #define X_GO(ST, AD, OF)                                                                                                  \
   do {                                                                                                                    \
     if constexpr (VB == 32 && NS == 1) {                                                                                  \
-      if (r12) { hipLaunchKernelGGL((conv_halo_x_kernel<H, VB, NT, NS, FLIP, ST, AD, OF, true>), grid, blk, 0, st, a, g, total); break; } \
+      if (r12) { hipLaunchKernelGGL((conv_halo_x_kernel<H, VB, NT, NS, FLIP, ST, AD, OF, true>), grid, blk, 0, st, a, g, total, XCe{}); break; } \
     }                                                                                                                     \
-    hipLaunchKernelGGL((conv_halo_x_kernel<H, VB, NT, NS, FLIP, ST, AD, OF, false>), grid, blk, 0, st, a, g, total);       \
+    hipLaunchKernelGGL((conv_halo_x_kernel<H, VB, NT, NS, FLIP, ST, AD, OF, false>), grid, blk, 0, st, a, g, total, XCe{});  \
   } while (0)
   if constexpr (!FLIP) {     // forward passes: InstanceNorm partials (16-bit output, no addend) or the fp32 logits
     if (stats) { X_GO(true, 0, false); return; }
@@ -612,4 +805,79 @@ void launch_conv_halo_x(ConvKArgs& a, hipStream_t st) {
 #undef X_DT
 }
 
+// ---- logits convolution with the cross-entropy fused into its epilogue --------------------------------------------------------
+bool conv_halo_x_ce_eligible(const ConvKArgs& a, int dtype, int nclass, int C) {
+  if (!conv_halo_x_eligible(a, dtype, nclass)) return false;
+  if (a.Cg != 16 || a.Cn != C || C > 12 || C < 2 || a.stats != nullptr || x_tap_order(a) != 0) return false;
+  if (a.add != nullptr && !(a.add == a.in && a.add_ld == a.g_ld && a.add_f32 == 0 && a.Cn_store * 2 <= 32)) return false;   // identity residual only
+  return true;
+}
+
+int conv_halo_x_ce_slots(const ConvKArgs& a) { return x_grid(a); }
+
+template <typename H> static void x_launch_ce(ConvKArgs& a, const XGeom& g, int total, dim3 grid, const XCe& e, hipStream_t st) {
+  const bool r12 = a.g_ld == 12, addc = a.add != nullptr;
+  const dim3 blk(256);
+#define X_CE(AD, R)                                                                                                         \
+  hipLaunchKernelGGL((conv_halo_x_kernel<H, 32, 1, 1, false, false, AD, true, R, true>), grid, blk, 0, st, a, g, total, e)
+  if (addc) { if (r12) X_CE(1, true); else X_CE(1, false); }
+  else { if (r12) X_CE(0, true); else X_CE(0, false); }
+#undef X_CE
+}
+
+void launch_conv_halo_x_ce(ConvKArgs& a, const XCe& e, hipStream_t st) {
+  XGeom g;
+  g.tyn = (a.Yr + X_TY - 1) / X_TY; g.tzn = (a.Zr + X_TZ - 1) / X_TZ;
+  g.tiles = x_tiles(a);
+  a.tiles = g.tiles;
+  g.in_sample_bytes = (int)((int64_t)a.Xi * a.Yi * a.Zi * a.g_ld * 2);
+  g.out_sample_bytes = 0;
+  g.add_sample_bytes = 0;
+  const int total = g.tiles * a.N;
+  const dim3 grid((unsigned)x_grid(a), 1u, 1u);
+  if (a.dtype == CTSEG_F16) x_launch_ce<F16>(a, g, total, grid, e, st); else x_launch_ce<BF16>(a, g, total, grid, e, st);
+}
+
 }  // namespace ctseg
+
+using namespace ctseg;
+
+static void x_fill(const ctseg_conv_desc* d, ConvKArgs& a) {
+  a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.add = (const char*)d->add;
+  a.stats = d->stats;
+  a.N = d->N; a.Xi = d->Xi; a.Yi = d->Yi; a.Zi = d->Zi; a.Xr = d->Xr; a.Yr = d->Yr; a.Zr = d->Zr; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo;
+  a.Cg = d->Cg; a.Cn = d->Cn; a.Cn_store = d->Cn_store; a.g_ld = d->g_ld; a.o_ld = d->o_ld; a.add_ld = d->add_ld;
+  a.sin = d->sin; a.sout = d->sout; a.rows = d->Xr * d->Yr * d->Zr; a.tiles = 0; a.out_f32 = d->out_f32; a.add_f32 = d->add_f32;
+  a.stats_ld = d->stats_ld; a.stats_tiles = d->stats_tiles; a.stats_tile0 = d->stats_tile0;
+  for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
+  a.out2 = nullptr; a.out2_col0 = 0; a.o2_ld = 0; a.dtype = d->dtype; a.xcd_order = 0;
+}
+
+extern "C" int ctseg_conv_logits_ce_slots(const ctseg_conv_desc* d, int32_t C) {
+  if (d == nullptr || d->nclass != 1) return 0;
+  ConvKArgs a;
+  x_fill(d, a);
+  a.stats = nullptr;
+  if (!conv_halo_x_ce_eligible(a, d->dtype, d->nclass, C)) return 0;
+  return conv_halo_x_ce_slots(a);
+}
+
+extern "C" int ctseg_conv_logits_ce(const ctseg_conv_desc* d, const uint8_t* labels, int32_t C, const float* class_weight,
+                                    const float* coef, int32_t coef_stride, void* dlogits, int32_t g_ld, double* part, int32_t P,
+                                    int32_t R, int64_t* cnt, void* stream) {
+  CTSEG_REQUIRE(d && d->in && d->w && labels && coef && dlogits && part && cnt, "conv_logits_ce: null pointer");
+  CTSEG_REQUIRE(d->nclass == 1, "conv_logits_ce: one tap class expected");
+  ConvKArgs a;
+  x_fill(d, a);
+  CTSEG_REQUIRE(conv_halo_x_ce_eligible(a, d->dtype, d->nclass, C), "conv_logits_ce: pass not eligible (ask ctseg_conv_logits_ce_slots)");
+  const int slots = conv_halo_x_ce_slots(a);
+  CTSEG_REQUIRE(P >= slots && R >= 2 && R <= 256, "conv_logits_ce: part needs >= %d slots per sample (P = %d)", slots, P);
+  CTSEG_REQUIRE(g_ld >= C && g_ld % 4 == 0 && ((uintptr_t)dlogits % 8) == 0 && d->Xo == d->Xr && d->Yo == d->Yr && d->Zo == d->Zr,
+                "conv_logits_ce: dlogits layout");
+  XCe e;
+  e.labels = labels; e.class_weight = class_weight; e.coef = coef; e.coef_stride = coef_stride; e.dlogits = (char*)dlogits;
+  e.g_ld = g_ld; e.part = part; e.P = P; e.R = R; e.cnt = (unsigned long long*)cnt; e.C = C;
+  launch_conv_halo_x_ce(a, e, (hipStream_t)stream);
+  CTSEG_LAUNCH_CHECK("conv_logits_ce");
+  return 0;
+}

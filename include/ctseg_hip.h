@@ -185,6 +185,20 @@ int ctseg_squash_masks(const uint8_t* masks, int32_t B, int32_t K, int64_t S, ui
 int ctseg_seg_loss(const float* logits, int32_t ld, const uint8_t* labels, int32_t B, int64_t S, int32_t C,
                    const float* class_weight, int32_t do_stats, double* part, int32_t P, int64_t* cnt, int32_t do_grad,
                    const float* coef, void* dlogits, int32_t g_ld, int32_t gdtype, uint8_t* pred_out, void* stream);
+/* The logits convolution of the U-Net's head with the cross-entropy of the training step fused into its epilogue: the fp32 logits
+ * (1.2 GB per step at 2 x 512 x 512 x 48) are never written or re-read.  Replaces, for the native training step, the pair
+ *   ctseg_conv_igemm(d) [monai UNet model.2.1.conv.unit0 + identity residual]  +  ctseg_seg_loss(do_stats = do_grad = 2)
+ *   [F.cross_entropy, capstone/models/losses.py:45-68; softmax -> argmax + Dice counts, training/utils.py:19-20, models/metrics.py:15-21]
+ * with the same per-voxel arithmetic: dlogits and cnt are bit-identical to the two-call path, the loss sums differ in summation
+ * order only.  d: the recorded descriptor of that convolution (d->out is not written).  labels [N][S] u8; class_weight [C] or NULL;
+ * coef[n * coef_stride] = d(loss)/d(weighted NLL sum of sample n); dlogits [N][S][g_ld] in d->dtype; part [N][P][R] doubles, this
+ * launch writes slots 0 .. ctseg_conv_logits_ce_slots()-1 of every sample (entries 0 = weighted NLL sum, 1 = weight sum, rest 0);
+ * cnt [N][3][C] += counts (zeroed by the caller).  ctseg_conv_logits_ce_slots: 0 when the pass is not eligible (the caller then
+ * keeps the two-call path), else the number of partial slots per sample the launch fills. */
+int ctseg_conv_logits_ce_slots(const ctseg_conv_desc* d, int32_t C);
+int ctseg_conv_logits_ce(const ctseg_conv_desc* d, const uint8_t* labels, int32_t C, const float* class_weight, const float* coef,
+                         int32_t coef_stride, void* dlogits, int32_t g_ld, double* part, int32_t P, int32_t R, int64_t* cnt,
+                         void* stream);
 /* cnt[B][3][C] += (|pred==c & true==c|, |pred==c|, |true==c|) from two u8 label maps [B][S]
  * (DiceMetricWrapper on squashed predictions, capstone/models/metrics.py:15-31); cnt zeroed by the caller. */
 int ctseg_dice_counts(const uint8_t* pred, const uint8_t* truth, int32_t B, int64_t S, int32_t C, int64_t* cnt, void* stream);
