@@ -87,7 +87,8 @@ struct XCe {
 };
 
 // ADD: 0 none, 1 the addend is the INPUT tensor (identity residual: taken from the centre voxel of the LDS halo), 2 a tensor in
-// global memory (bf16/half like the input, or fp32 when P.add_f32).
+// global memory (bf16/half like the input, or fp32 when P.add_f32) loaded by the epilogue, 3 a 16-bit tensor staged by LDS-DMA
+// beside the halo of its tile (ordinary loads inside the DMA pipeline make the compiler drain it: 0.27 vs 0.17 ms on 32 -> 32).
 // A wave owns the x-column of one y pair for NT 16-column blocks of the output; NS such wave groups (4 waves each) split the
 // column blocks of a wider output between them.  Measured on 32 -> 32 at 2 x 256 x 256 x 24 (ms per launch, register-staged kernel
 // 0.22): NT = 1, NS = 2 with the weights in registers 0.165 (220-246 VGPRs: the operand reads sit right in front of their MFMAs);
@@ -100,12 +101,13 @@ struct XCe {
 template <typename H, int VB, int NT, int NS, bool FLIP, bool STATS, int ADD, bool OF32, bool R12, bool CE = false>
 __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P, const XGeom G, int total_tiles, const XCe E) {
   static_assert(!R12 || (VB == 32 && NS == 1), "12-wide rows: 16 gathered channels, one wave group");
-  static_assert(!CE || (VB == 32 && NS == 1 && NT == 1 && !FLIP && !STATS && ADD != 2), "fused cross-entropy: the logits convolution");
+  static_assert(!CE || (VB == 32 && NS == 1 && NT == 1 && !FLIP && !STATS && ADD < 2), "fused cross-entropy: the logits convolution");
+  static_assert(ADD != 3 || (!R12 && !CE), "DMA-staged addend: the DMA pipeline only");
   using CF = XCfg<VB>;
   // WL: the packed weights live in LDS in FRAGMENT order (1 KB per (column block, dx, K-step group): lane l reads its 16 bytes at
   // l * 16, conflict free by construction) instead of in registers: 54 fragments = 216 registers per lane do not fit beside the
   // operand prefetch (MFMA A/B operands come from the 256 architectural VGPRs)
-  constexpr bool WL = NT * NS * 3 * CF::TYPES > 16;
+  constexpr bool WL = false;     // weights in registers (see above: the same speed, and the LDS goes to the addend staging of ADD == 3)
   constexpr int NTA = NT * NS;                           // column blocks of the workgroup
   constexpr int WBYTES = WL ? NTA * 3 * CF::TYPES * 1024 : 0;
   constexpr int NPL = CF::NPL, TYPES = CF::TYPES, NW = 4 * NS, NTHR = 64 * NW;
@@ -114,9 +116,15 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
   static_assert(CF::NPIECE % NWD == 0, "every DMA wave issues the same number of pieces (counted vmcnt)");
   constexpr int OSZ = OF32 ? 4 : 2;
 
+  // ADD == 3: the addend tile (X_TX x 8 x 8 voxels, the workgroup's 16 * NTA channels) in 16-byte chunks, voxel-major, two buffers
+  constexpr int ACH = 2 * NTA;                               // chunks per voxel
+  constexpr int ABUF = ADD == 3 ? X_TX * 64 * ACH * 16 : 0;
+  constexpr int APIECES = X_TX * 64 * ACH / 64, APW = ADD == 3 ? APIECES / NW : 0;
+  static_assert(ADD != 3 || APIECES % NW == 0, "every wave issues the same number of addend pieces");
   constexpr int CE_T = CE ? NW * X_TX * 16 * 48 : 0;        // per-wave transpose scratch: 12 fp32 logits per voxel
   constexpr int CE_B = CE ? 3 * 16 * 4 + NW * 2 * 8 : 0;     // Dice counters, per-wave loss sums
-  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B];
+  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B + 2 * ABUF];
+  char* const sA = smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B;
   char* const sW = smem + 2 * CF::HALO;
   float* const sStats = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES);     // per-wave statistics slots
   char* const sT = smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4;
@@ -190,6 +198,17 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     const int hy = rem / X_HZ, hz = rem - hy * X_HZ;
     poff[j] = ((hx * YZ + hy * P.Zi + hz) * P.g_ld + pl * 8) * 2;
     phot[j] = hv < X_HV ? ((1u << hx) | (1u << (6 + hy)) | (1u << (16 + hz))) : 0x80000000u;
+  }
+  int apoff[APW > 0 ? APW : 1];
+  uint32_t aphot[APW > 0 ? APW : 1];
+  if constexpr (ADD == 3) {
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+      const int ci = (wave + j * NW) * 64 + lane, tv = ci / ACH, ch = ci - tv * ACH;
+      const int ix = tv >> 6, iy = (tv >> 3) & 7, iz = tv & 7;
+      apoff[j] = ((ix * P.Yo + iy) * P.Zo + iz) * P.add_ld * 2 + (blockIdx.y * ACH + ch) * 16;
+      aphot[j] = (1u << ix) | (1u << (4 + iy)) | (1u << (12 + iz));
+    }
   }
   // R12 staging: 3 eight-byte pieces per halo voxel (bytes 0-7, 8-15 -> plane 0; 16-23 -> plane 1), voxel-major so that a wave's
   // loads run along the 240-byte z rows of the volume
@@ -291,6 +310,17 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
       const int vo = (phot[j] & notm) == 0u ? poff[j] : (int)0x80000000;
       x_raw_buffer_load_lds(rs, (x_lds_u32_ptr)(dst + (piece / X_PIECES) * X_PLANE + (piece % X_PIECES) * 1024), 16, vo, soff, 0, 0);
     }
+    if constexpr (ADD == 3) {      // the addend of the same tile, consumed (into registers) at the end of its multiplies
+      const uint32_t am = range_mask(0, P.Xr - o.x0 - 1, X_TX) | (range_mask(0, P.Yr - o.y0 - 1, 8) << 4) | (range_mask(0, P.Zr - o.z0 - 1, 8) << 12);
+      const uint32_t anot = ~am;
+      const xi32x4 ars = x_make_rsrc(P.add + (int64_t)o.n * G.add_sample_bytes, (uint32_t)G.add_sample_bytes);
+      const int asoff = ((o.x0 * P.Yo + o.y0) * P.Zo + o.z0) * P.add_ld * 2;
+#pragma unroll
+      for (int j = 0; j < APW; ++j) {
+        const int vo = (aphot[j] & anot) == 0u ? apoff[j] : (int)0x80000000;
+        x_raw_buffer_load_lds(ars, (x_lds_u32_ptr)(sA + buf * ABUF + (wave + j * NW) * 1024), 16, vo, asoff, 0, 0);
+      }
+    }
   };
 
   u32x2 rg[R_J];
@@ -363,7 +393,7 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
           wsq[j][q] += sv * sv;
         }
       }
-      if constexpr (ADD == 1) {
+      if constexpr (ADD == 1 || ADD == 3) {
         v[0] += h2f<H>(cadd[j][i][0] & 0xffffu); v[1] += h2f<H>(cadd[j][i][0] >> 16);
         v[2] += h2f<H>(cadd[j][i][1] & 0xffffu); v[3] += h2f<H>(cadd[j][i][1] >> 16);
       } else if constexpr (ADD == 2) {
@@ -440,6 +470,12 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < X_TX; ++i) cadd[j][i] = *reinterpret_cast<const u32x2*>(hb + cbase + 2 * j * X_PLANE + i * X_XSTRIDE);
+    } else if constexpr (ADD == 3) {
+      const char* ab = sA + buf * ABUF + (((2 * yp + pdy) * 8 + pz) * ACH) * 16 + (ns * NT * 16 + 4 * q4) * 2;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < X_TX; ++i) cadd[j][i] = *reinterpret_cast<const u32x2*>(ab + i * 64 * ACH * 16 + j * 32);
     }
   };
 
@@ -758,7 +794,10 @@ static void x_launch(ConvKArgs& a, const XGeom& g, int total, dim3 grid, hipStre
   const bool stats = a.stats != nullptr, of32 = a.out_f32 != 0;
   // identity residual: the addend is the input tensor itself, every stored channel is present in the staged voxel
   const bool addc = a.add == a.in && a.add_ld == a.g_ld && a.add_f32 == 0 && a.Cn_store * 2 <= VB && grid.y == 1;
-  const int add = a.add == nullptr ? 0 : (addc ? 1 : 2);
+  // a 16-bit addend whose rows hold whole 16-byte chunks goes through the DMA pipeline (64-byte voxels: the LDS has room for it)
+  const bool add_dma = VB == 64 && !of32 && !stats && a.add != nullptr && !addc && a.add_f32 == 0 && (a.add_ld * 2) % 16 == 0 && ((uintptr_t)a.add % 16) == 0 &&
+                       a.add_ld >= 16 * NT * NS && a.g_ld != 12;
+  const int add = a.add == nullptr ? 0 : (addc ? 1 : (add_dma ? 3 : 2));
   const dim3 blk(256 * NS);
   const bool r12 = a.g_ld == 12;
 #define X_GO(ST, AD, OF)                                                                                                  \
@@ -775,7 +814,10 @@ static void x_launch(ConvKArgs& a, const XGeom& g, int total, dim3 grid, hipStre
       return;
     }
   }
-  if (add == 1) X_GO(false, 1, false); else if (add == 2) X_GO(false, 2, false); else X_GO(false, 0, false);
+  if (add == 1) X_GO(false, 1, false);
+  else if (add == 2) X_GO(false, 2, false);
+  else if (add == 3) { if constexpr (VB == 64) hipLaunchKernelGGL((conv_halo_x_kernel<H, VB, NT, NS, FLIP, false, 3, false, false>), grid, blk, 0, st, a, g, total, XCe{}); }
+  else X_GO(false, 0, false);
 #undef X_GO
 }
 
