@@ -493,6 +493,8 @@ class Plan:
                     hooks[a]()
                 busy = True
             if self.bwd[a][0] in self.SIDE_OPS:
+                if os.environ.get("CTSEG_TIMING_SKIP_SIDE") == "1":      # timing-only: what the weight-gradient stream costs the step
+                    continue
                 ev = self._side_ev.get(a)
                 if ev is None:
                     ev = self._side_ev[a] = torch.cuda.Event()

@@ -12,6 +12,10 @@
 // contiguous 32-byte rows (256 B): bank-conflict free.  One fp32 slab per workgroup -> ctseg_conv_wgrad_reduce.
 #include "ctseg_dev.h"
 
+#ifndef WH_ABL
+#define WH_ABL 0     // timing-only ablation of conv_wgrad_head_kernel: 1 = no MFMAs, 2 = no LDS operand reads, 4 = no global loads, 8 = no LDS staging stores
+#endif
+
 namespace ctseg {
 
 struct WgradHaloArgs {
@@ -227,6 +231,170 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The 16 -> <= 16 channel layer at full resolution (the logits convolution of the head: 25 M voxels, 1.2 GB of operands, 348 GFLOP of
+// padded MFMA work) is HBM-latency bound in the kernel above: a tile's loads are issued one tile (~900 cycles of multiplies) before
+// they are written to LDS, against ~3 us of memory latency, and two workgroups per CU keep 54 KB in flight (0.65 ms; 1.10 ms with one
+// workgroup per CU).  This variant keeps TWO tiles of loads in flight per workgroup in two register sets (tile t+2 is requested at
+// the top of iteration t and written to LDS at the end of iteration t+1), moves rows in 8-byte pieces with raw buffer loads — 12-wide
+// (24-byte) and 16-wide rows alike, a voxel outside the volume is an out-of-range offset selected by one v_and / v_cmp / v_cndmask —
+// and has no per-load branches.  The multiplies are those of conv_wgrad_halo_kernel<32, 32>.
+template <int NPX, int NPD>      // 8-byte pieces per x / dy voxel row: 3 (12 wide) or 4 (16 wide)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_wgrad_head_kernel(const WgradHaloArgs P, int total_tiles, int x_sample_bytes, int d_sample_bytes) {
+  constexpr int XBYTES = WH_HV * 32, DBYTES = WH_TV * 32, BUF = XBYTES + DBYTES;
+  constexpr int XN = WH_HV * NPX, DN = WH_TV * NPD, JX = (XN + 255) / 256, JD = (DN + 255) / 256;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef s16x4 __attribute__((address_space(3)))* lds_s16x4;
+  __shared__ __attribute__((aligned(16))) char smem[BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int tq = r16 >> 2, tp = r16 & 3;
+  const int YZ = P.Y * P.Z;
+
+  int xo[JX], xl[JX], dof[JD], dl[JD];
+  uint32_t xh[JX], dh[JD];
+#pragma unroll
+  for (int j = 0; j < JX; ++j) {
+    const int idx = tid + j * 256, hv = idx / NPX, part = idx - hv * NPX;
+    const int hx = hv / 100, rem = hv - hx * 100, hy = rem / 10, hz = rem - hy * 10;
+    xo[j] = (hx * YZ + hy * P.Z + hz) * P.g_ld * 2 + part * 8;
+    xh[j] = idx < XN ? ((1u << hx) | (1u << (6 + hy)) | (1u << (16 + hz))) : 0x80000000u;
+    xl[j] = hv * 32 + part * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < JD; ++j) {
+    const int idx = tid + j * 256, tv = idx / NPD, part = idx - tv * NPD;
+    const int tx = tv >> 6, ty = (tv >> 3) & 7, tz = tv & 7;
+    dof[j] = (tx * YZ + ty * P.Z + tz) * P.d_ld * 2 + part * 8;
+    dh[j] = idx < DN ? ((1u << tx) | (1u << (4 + ty)) | (1u << (12 + tz))) : 0x80000000u;
+    dl[j] = XBYTES + tv * 32 + part * 8;
+  }
+  const int bias_bytes = (YZ + P.Z + 1) * P.g_ld * 2;
+  auto range_mask = [](int lo, int hi, int nbits) -> uint32_t {
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > nbits - 1 ? nbits - 1 : hi;
+    return hi < lo ? 0u : ((2u << hi) - (1u << lo));
+  };
+  auto gload = [&](int t, u32x2 (&rx)[JX], u32x2 (&rd)[JD]) {
+    const int n = t / P.tiles;
+    int r = t - n * P.tiles;
+    const int tz = r % P.tzn; r /= P.tzn;
+    const int ty = r % P.tyn, tx = r / P.tyn;
+    const int x0 = tx * 4, y0 = ty * 8, z0 = tz * 8;
+    const uint32_t xm = ~(range_mask(1 - x0, P.X - x0, 6) | (range_mask(1 - y0, P.Y - y0, 10) << 6) | (range_mask(1 - z0, P.Z - z0, 10) << 16));
+    const uint32_t dm = ~(range_mask(0, P.X - x0 - 1, 4) | (range_mask(0, P.Y - y0 - 1, 8) << 4) | (range_mask(0, P.Z - z0 - 1, 8) << 12));
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.in) + (int64_t)n * x_sample_bytes - bias_bytes, 0,
+                                                                         x_sample_bytes + bias_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.dy) + (int64_t)n * d_sample_bytes, 0, d_sample_bytes,
+                                                                         0x00020000);
+    const int xs = ((x0 * P.Y + y0) * P.Z + z0) * P.g_ld * 2, dsf = ((x0 * P.Y + y0) * P.Z + z0) * P.d_ld * 2;
+#pragma unroll
+    for (int j = 0; j < JX; ++j)
+      rx[j] = (WH_ABL & 4) ? u32x2{(uint32_t)xs, 0u} : __builtin_amdgcn_raw_buffer_load_b64(xr, (xh[j] & xm) == 0u ? xo[j] : (int)0x80000000, xs, 0);
+#pragma unroll
+    for (int j = 0; j < JD; ++j)
+      rd[j] = (WH_ABL & 4) ? u32x2{(uint32_t)dsf, 0u} : __builtin_amdgcn_raw_buffer_load_b64(dr, (dh[j] & dm) == 0u ? dof[j] : (int)0x80000000, dsf, 0);
+  };
+  auto sstore = [&](const u32x2 (&rx)[JX], const u32x2 (&rd)[JD]) {
+    if (WH_ABL & 8) { if (rx[0][0] == 0x12345u && rd[0][0] == 0x54321u) smem[tid] = 1; return; }
+#pragma unroll
+    for (int j = 0; j < JX; ++j)
+      if (JX * 256 == XN || tid + j * 256 < XN) *reinterpret_cast<u32x2*>(smem + xl[j]) = rx[j];
+#pragma unroll
+    for (int j = 0; j < JD; ++j)
+      if (JD * 256 == DN || tid + j * 256 < DN) *reinterpret_cast<u32x2*>(smem + dl[j]) = rd[j];
+  };
+
+  f32x4 acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lz = 4 * (q4 & 1) + tq, ly = q4 >> 1;
+  s16x8 ones;
+  {
+    const short o = (r16 == 0) ? (short)0x3f80 : (short)0;
+    ones = s16x8{o, o, o, o, o, o, o, o};
+  }
+  auto compute = [&]() {
+    const char* xs = smem;
+    const char* ds = xs + XBYTES;
+#pragma unroll 2
+    for (int s = 0; s < 8; ++s) {
+      const int x = s >> 1, yb = 4 * (s & 1);
+      bf16x8 df;
+      {
+        const char* p0 = ds + (((x * 8) + (yb + ly)) * 8 + lz) * 32 + tp * 8;
+        const s16x4 lo = (WH_ABL & 2) ? s16x4{(short)s, 1, 2, 3} : __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+        const s16x4 hi = (WH_ABL & 2) ? s16x4{(short)s, 1, 2, 3} : __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 2 * 8 * 32));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        df = __builtin_bit_cast(bf16x8, v);
+      }
+      const int hbase = (((x + 1) * 10) + (yb + ly + 1)) * 10 + (lz + 1);
+      bf16x8 af[6];
+#pragma unroll
+      for (int ti = 0; ti < 6; ++ti) {
+        const char* p0 = xs + (hbase + P.delta[wave + 4 * ti]) * 32 + tp * 8;
+        const s16x4 lo = (WH_ABL & 2) ? s16x4{(short)(s + tp), 1, 2, 3} : __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+        const s16x4 hi = (WH_ABL & 2) ? s16x4{(short)(s + tp), 1, 2, 3} : __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 2 * 10 * 32));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        af[ti] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int ti = 0; ti < 6; ++ti) {
+        if constexpr ((WH_ABL & 1) != 0) acc[ti][0] += __builtin_bit_cast(f32x4, af[ti])[0] * __builtin_bit_cast(f32x4, df)[1];
+        else acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ti], df, acc[ti], 0, 0, 0);
+      }
+      const int tap = wave + 24;
+      if (tap < 27) {
+        const char* p0 = xs + (hbase + P.delta[tap]) * 32 + tp * 8;
+        const s16x4 lo = (WH_ABL & 2) ? s16x4{(short)(s + tp), 1, 2, 3} : __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+        const s16x4 hi = (WH_ABL & 2) ? s16x4{(short)(s + tp), 1, 2, 3} : __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 2 * 10 * 32));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        acc[6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), df, acc[6], 0, 0, 0);
+      } else {   // pseudo tap 27: row 0 accumulates sum(dy) (bias gradient)
+        acc[6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), df, acc[6], 0, 0, 0);
+      }
+    }
+  };
+
+  int t = blockIdx.x, tstride = gridDim.x, tlast = total_tiles;
+  if ((gridDim.x & 7) == 0) {
+    const int chunk = (total_tiles + 7) / 8, xcd = blockIdx.x & 7;
+    t = xcd * chunk + (blockIdx.x >> 3);
+    tstride = gridDim.x >> 3;
+    tlast = (xcd + 1) * chunk < total_tiles ? (xcd + 1) * chunk : total_tiles;
+  }
+  // rows narrower than 32 bytes: the pad bytes of every slot are zero for the whole launch
+  if (NPX < 4) for (int i = tid; i < WH_HV; i += 256) *reinterpret_cast<u32x2*>(smem + i * 32 + 24) = u32x2{0u, 0u};
+  if (NPD < 4) for (int i = tid; i < WH_TV; i += 256) *reinterpret_cast<u32x2*>(smem + XBYTES + i * 32 + 24) = u32x2{0u, 0u};
+  // ONE register set of loads in flight per workgroup, FOUR workgroups per CU (128 registers each): the phases of a workgroup
+  // (loads -> multiplies -> barrier -> LDS stores -> barrier) do not overlap inside it; they overlap with the other three's.
+  u32x2 rxA[JX], rdA[JD];
+  if (t < tlast) {
+    gload(t, rxA, rdA);
+    sstore(rxA, rdA);
+  }
+  __syncthreads();
+  for (; t < tlast; t += tstride) {
+    if (t + tstride < tlast) gload(t + tstride, rxA, rdA);
+    compute();
+    __syncthreads();
+    if (t + tstride < tlast) sstore(rxA, rdA);
+    __syncthreads();
+  }
+
+  float* slab = P.ws + (int64_t)blockIdx.x * P.kpad_w * P.cn_pad;
+#pragma unroll
+  for (int ti = 0; ti < 7; ++ti) {
+    const int tap = wave + 4 * ti;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = tap * P.Cg + 4 * q4 + e;
+      if (row < P.kpad_w) slab[(int64_t)row * P.cn_pad + r16] = acc[ti][e];
+    }
+  }
+}
+
 bool wgrad_halo_eligible(const ctseg_wgrad_desc* d) {
   if (d->dtype != CTSEG_BF16 || d->ntaps != 27 || d->sin != 1) return false;
   const int vb = d->Cg * 2, db = ((d->Cn + 15) / 16) * 32;
@@ -251,7 +419,10 @@ static int wgrad_halo_grid(const ctseg_wgrad_desc* d) {
   const int vb = d->Cg * 2, db = ((d->Cn + 15) / 16) * 32;
   // more workgroups per CU than this measured no faster with the single staging buffer (0.245 / 0.250 / 0.255 ms at 1 / 2 / 3
   // per CU for the 32->32 layer); the smaller LDS footprint is kept for what it leaves to the main stream's kernels
-  const int per_cu = (vb + db <= 64) ? 2 : 1;
+  int per_cu = (vb + db <= 64) ? 2 : 1;
+  if (vb == 32 && db == 32 && getenv("CTSEG_WGRAD_HEAD_OLD") == nullptr && (d->g_ld == 12 || d->g_ld == 16) && (d->d_ld == 12 || d->d_ld == 16))
+    per_cu = 4;      // conv_wgrad_head_kernel: 27 KB of LDS and 128 registers per workgroup
+  if (const char* e = getenv("CTSEG_WH_PER_CU")) per_cu = atoi(e);
   int g = 256 * per_cu;
   return g < tiles ? g : tiles;
 }
@@ -275,7 +446,13 @@ void launch_wgrad_halo(const ctseg_wgrad_desc* d, hipStream_t st) {
   }
   const int total = a.tiles * d->N, grid = wgrad_halo_grid(d);
   const int vb = d->Cg * 2, db = ((d->Cn + 15) / 16) * 32;
-  if (vb == 32 && db == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<32, 32>), dim3(grid), dim3(256), 0, st, a, total);
+  if (vb == 32 && db == 32 && getenv("CTSEG_WGRAD_HEAD_OLD") == nullptr && (d->g_ld == 12 || d->g_ld == 16) && (d->d_ld == 12 || d->d_ld == 16)) {
+    const int xsb = (int)((int64_t)d->Xi * d->Yi * d->Zi * d->g_ld * 2), dsb = (int)((int64_t)d->Xi * d->Yi * d->Zi * d->d_ld * 2);
+#define WH_GO(NX, ND) hipLaunchKernelGGL((conv_wgrad_head_kernel<NX, ND>), dim3(grid), dim3(256), 0, st, a, total, xsb, dsb)
+    if (d->g_ld == 12) { if (d->d_ld == 12) WH_GO(3, 3); else WH_GO(3, 4); }
+    else { if (d->d_ld == 12) WH_GO(4, 3); else WH_GO(4, 4); }
+#undef WH_GO
+  } else if (vb == 32 && db == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<32, 32>), dim3(grid), dim3(256), 0, st, a, total);
   else if (vb == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<32, 64>), dim3(grid), dim3(256), 0, st, a, total);
   else if (db == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<64, 32>), dim3(grid), dim3(256), 0, st, a, total);
   else hipLaunchKernelGGL((conv_wgrad_halo_kernel<64, 64>), dim3(grid), dim3(256), 0, st, a, total);
