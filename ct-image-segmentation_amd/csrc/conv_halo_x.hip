@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
   constexpr int ABUF = ADD == 3 ? X_TX * 64 * ACH * 16 : 0;
   constexpr int APIECES = X_TX * 64 * ACH / 64, APW = ADD == 3 ? APIECES / NW : 0;
   static_assert(ADD != 3 || APIECES % NW == 0, "every wave issues the same number of addend pieces");
-  constexpr int CE_T = CE ? NW * X_TX * 16 * 48 : 0;        // per-wave transpose scratch: 12 fp32 logits per voxel
+  constexpr int CE_T = CE ? NW * 2 * 16 * 48 : 0;           // per-wave exchange scratch: 12 fp32 logits per voxel, two x planes at a time
   constexpr int CE_B = CE ? 3 * 16 * 4 + NW * 2 * 8 : 0;     // Dice counters, per-wave loss sums
   __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B + 2 * ABUF];
   char* const sA = smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B;
@@ -521,23 +521,30 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     }
     // logits = conv + bias (+ identity residual), then a wave-local exchange through LDS: lane (r16, q4) ends up with the 12 values
     // of voxel r16 of x plane q4 (it held channels 4 q4 .. 4 q4 + 3 of all four planes)
-    char* sc = sT + wave * (X_TX * 16 * 48);
-#pragma unroll
-    for (int i = 0; i < X_TX; ++i) {
-      f32x4 v;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = acc[0][i][q] + bias[0][q];
-      if constexpr (ADD == 1) {
-        v[0] += h2f<H>(cadd[0][i][0] & 0xffffu); v[1] += h2f<H>(cadd[0][i][0] >> 16);
-        v[2] += h2f<H>(cadd[0][i][1] & 0xffffu); v[3] += h2f<H>(cadd[0][i][1] >> 16);
-      }
-      if (q4 < 3) *reinterpret_cast<f32x4*>(sc + (i * 16 + r16) * 48 + q4 * 16) = v;
-    }
+    // (two rounds of two planes: 1.5 KB of scratch per wave, so that three workgroups fit a CU; lanes q4 = 2r, 2r+1 read in round r)
+    char* sc = sT + wave * (2 * 16 * 48);
     float x[12];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(sc + (q4 * 16 + r16) * 48 + q * 16);
-      x[4 * q] = v[0]; x[4 * q + 1] = v[1]; x[4 * q + 2] = v[2]; x[4 * q + 3] = v[3];
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * r + ii;
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[0][i][q] + bias[0][q];
+        if constexpr (ADD == 1) {
+          v[0] += h2f<H>(cadd[0][i][0] & 0xffffu); v[1] += h2f<H>(cadd[0][i][0] >> 16);
+          v[2] += h2f<H>(cadd[0][i][1] & 0xffffu); v[3] += h2f<H>(cadd[0][i][1] >> 16);
+        }
+        if (q4 < 3) *reinterpret_cast<f32x4*>(sc + (ii * 16 + r16) * 48 + q4 * 16) = v;
+      }
+      if ((q4 >> 1) == r) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sc + ((q4 & 1) * 16 + r16) * 48 + q * 16);
+          x[4 * q] = v[0]; x[4 * q + 1] = v[1]; x[4 * q + 2] = v[2]; x[4 * q + 3] = v[3];
+        }
+      }
     }
     const int C = E.C;
     const int xg = o.x0 + q4, yg = o.y0 + 2 * yp + pdy, zg = o.z0 + pz;
@@ -855,7 +862,12 @@ bool conv_halo_x_ce_eligible(const ConvKArgs& a, int dtype, int nclass, int C) {
   return true;
 }
 
-int conv_halo_x_ce_slots(const ConvKArgs& a) { return x_grid(a); }
+static int x_grid_ce(const ConvKArgs& a) {     // 48 KB of LDS but ~230 registers per lane (weights + the softmax's arrays): two workgroups per CU
+  const int total = x_tiles(a) * a.N, gx = 256 * 2;
+  return gx > total ? total : gx;
+}
+
+int conv_halo_x_ce_slots(const ConvKArgs& a) { return x_grid_ce(a); }
 
 template <typename H> static void x_launch_ce(ConvKArgs& a, const XGeom& g, int total, dim3 grid, const XCe& e, hipStream_t st) {
   const bool r12 = a.g_ld == 12, addc = a.add != nullptr;
@@ -876,7 +888,7 @@ void launch_conv_halo_x_ce(ConvKArgs& a, const XCe& e, hipStream_t st) {
   g.out_sample_bytes = 0;
   g.add_sample_bytes = 0;
   const int total = g.tiles * a.N;
-  const dim3 grid((unsigned)x_grid(a), 1u, 1u);
+  const dim3 grid((unsigned)x_grid_ce(a), 1u, 1u);
   if (a.dtype == CTSEG_F16) x_launch_ce<F16>(a, g, total, grid, e, st); else x_launch_ce<BF16>(a, g, total, grid, e, st);
 }
 
