@@ -30,12 +30,15 @@ struct WgradHaloArgs {
 
 constexpr int WH_HV = 600, WH_TV = 256;
 
-template <int VB, int DBY>
-__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArgs P, int total_tiles) {
+// NW waves split the 27 taps (+ the all-ones pseudo tap): 4 waves x 7 taps, or 8 waves x 3-4 taps.  With 64-byte operands the 7-tap
+// accumulators (112 registers) left one wave per SIMD (302 registers): 8 waves with <= 4 taps each fit two per SIMD.
+template <int VB, int DBY, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad_halo_kernel(const WgradHaloArgs P, int total_tiles) {
+  constexpr int NTH = 64 * NW, TPW = (28 + NW - 1) / NW, TFULL = 27 / NW;    // taps per wave; taps every wave owns (the last may not exist)
   constexpr int PA = VB / 32, PB = DBY / 32;
   constexpr int XBYTES = PA * WH_HV * 32, DBYTES = PB * WH_TV * 32, BUF = XBYTES + DBYTES;
   constexpr int XCH = WH_HV * (VB / 16), DCH = WH_TV * (DBY / 16);
-  constexpr int JX = (XCH + 255) / 256, JD = (DCH + 255) / 256;
+  constexpr int JX = (XCH + NTH - 1) / NTH, JD = (DCH + NTH - 1) / NTH;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   typedef s16x4 __attribute__((address_space(3)))* lds_s16x4;
 
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
   int gx_byte[JX], gx_hxyz[JX], gx_lds[JX], gd_byte[JD], gd_xyz[JD], gd_lds[JD];
 #pragma unroll
   for (int j = 0; j < JX; ++j) {
-    const int idx = tid + j * 256;
+    const int idx = tid + j * NTH;
     const int c = idx % (VB / 16), hv = idx / (VB / 16);
     const int hx = hv / 100, rem = hv - hx * 100, hy = rem / 10, hz = rem - hy * 10;
     gx_byte[j] = (((hx - 1) * YZ + (hy - 1) * P.Z + (hz - 1)) * P.g_ld + c * 8) * 2;
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
   }
 #pragma unroll
   for (int j = 0; j < JD; ++j) {
-    const int idx = tid + j * 256;
+    const int idx = tid + j * NTH;
     const int c = idx % (DBY / 16), tv = idx / (DBY / 16);
     const int tx = tv >> 6, ty = (tv >> 3) & 7, tz = tv & 7;
     gd_byte[j] = ((tx * YZ + ty * P.Z + tz) * P.d_ld + c * 8) * 2;
@@ -109,15 +112,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
     char* ds = xs + XBYTES;
 #pragma unroll
     for (int j = 0; j < JX; ++j)
-      if (JX * 256 == XCH || tid + j * 256 < XCH) *reinterpret_cast<u32x4*>(xs + gx_lds[j]) = rx[j];
+      if (JX * NTH == XCH || tid + j * NTH < XCH) *reinterpret_cast<u32x4*>(xs + gx_lds[j]) = rx[j];
 #pragma unroll
     for (int j = 0; j < JD; ++j)
-      if (JD * 256 == DCH || tid + j * 256 < DCH) *reinterpret_cast<u32x4*>(ds + gd_lds[j]) = rd[j];
+      if (JD * NTH == DCH || tid + j * NTH < DCH) *reinterpret_cast<u32x4*>(ds + gd_lds[j]) = rd[j];
   };
 
-  f32x4 acc[7][PA][PB];
+  f32x4 acc[TPW][PA][PB];
 #pragma unroll
-  for (int t = 0; t < 7; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int a = 0; a < PA; ++a)
 #pragma unroll
@@ -166,10 +169,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
       const int hbase = (((x + 1) * 10) + (yb + ly + 1)) * 10 + (lz + 1);
       // taps wave, wave+4, ..., wave+20 always exist: fetch all their operands first, then issue the MFMAs back to back
       // (branch-free, so the LDS latency of one tap hides behind the others); tap wave+24 may be the pseudo tap 27
-      bf16x8 af[6][PA];
+      bf16x8 af[TFULL][PA];
 #pragma unroll
-      for (int ti = 0; ti < 6; ++ti) {
-        const int h = hbase + P.delta[wave + 4 * ti];
+      for (int ti = 0; ti < TFULL; ++ti) {
+        const int h = hbase + P.delta[wave + NW * ti];
 #pragma unroll
         for (int a = 0; a < PA; ++a) {
           const char* p0 = xs + a * (WH_HV * 32) + h * 32 + tp * 8;
@@ -180,14 +183,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
         }
       }
 #pragma unroll
-      for (int ti = 0; ti < 6; ++ti)
+      for (int ti = 0; ti < TFULL; ++ti)
 #pragma unroll
         for (int a = 0; a < PA; ++a)
 #pragma unroll
           for (int b = 0; b < PB; ++b)
             acc[ti][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ti][a], df[b], acc[ti][a][b], 0, 0, 0);
-      {
-        const int tap = wave + 24;
+      if constexpr (TPW > TFULL) {
+        const int tap = wave + NW * TFULL;      // wave-uniform: a real tap, the pseudo tap 27, or nothing
         if (tap < 27) {
           const int h = hbase + P.delta[tap];
 #pragma unroll
@@ -198,12 +201,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
             const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const bf16x8 a6 = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
-            for (int b = 0; b < PB; ++b) acc[6][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a6, df[b], acc[6][a][b], 0, 0, 0);
+            for (int b = 0; b < PB; ++b) acc[TFULL][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a6, df[b], acc[TFULL][a][b], 0, 0, 0);
           }
-        } else {  // pseudo tap 27: x == 1 on channel row 0 -> row 0 of the tile accumulates sum(dy) (bias gradient)
+        } else if (tap == 27) {  // pseudo tap 27: x == 1 on channel row 0 -> row 0 of the tile accumulates sum(dy) (bias gradient)
 #pragma unroll
           for (int b = 0; b < PB; ++b)
-            acc[6][0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), df[b], acc[6][0][b], 0, 0, 0);
+            acc[TFULL][0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), df[b], acc[TFULL][0][b], 0, 0, 0);
         }
       }
     }
@@ -215,8 +218,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
   // ---- one slab per workgroup: lane holds column c16 = dy channel, rows 4*q4 + e = x channel ------------------------
   float* slab = P.ws + (int64_t)blockIdx.x * P.kpad_w * P.cn_pad;
 #pragma unroll
-  for (int ti = 0; ti < 7; ++ti) {
-    const int tap = wave + 4 * ti;
+  for (int ti = 0; ti < TPW; ++ti) {
+    const int tap = wave + NW * ti;
+    if (tap > 27) continue;
 #pragma unroll
     for (int a = 0; a < PA; ++a) {
       if (tap == 27 && a > 0) continue;
@@ -452,10 +456,11 @@ void launch_wgrad_halo(const ctseg_wgrad_desc* d, hipStream_t st) {
     if (d->g_ld == 12) { if (d->d_ld == 12) WH_GO(3, 3); else WH_GO(3, 4); }
     else { if (d->d_ld == 12) WH_GO(4, 3); else WH_GO(4, 4); }
 #undef WH_GO
-  } else if (vb == 32 && db == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<32, 32>), dim3(grid), dim3(256), 0, st, a, total);
-  else if (vb == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<32, 64>), dim3(grid), dim3(256), 0, st, a, total);
-  else if (db == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<64, 32>), dim3(grid), dim3(256), 0, st, a, total);
-  else hipLaunchKernelGGL((conv_wgrad_halo_kernel<64, 64>), dim3(grid), dim3(256), 0, st, a, total);
+  } else if (vb == 32 && db == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<32, 32, 4>), dim3(grid), dim3(256), 0, st, a, total);
+  else if (vb == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<32, 64, 4>), dim3(grid), dim3(256), 0, st, a, total);
+  else if (db == 32) hipLaunchKernelGGL((conv_wgrad_halo_kernel<64, 32, 4>), dim3(grid), dim3(256), 0, st, a, total);
+  else if (getenv("CTSEG_WGRAD_HALO_4W") != nullptr) hipLaunchKernelGGL((conv_wgrad_halo_kernel<64, 64, 4>), dim3(grid), dim3(256), 0, st, a, total);
+  else hipLaunchKernelGGL((conv_wgrad_halo_kernel<64, 64, 8>), dim3(grid), dim3(512), 0, st, a, total);
 }
 
 }  // namespace ctseg
