@@ -294,7 +294,7 @@ class _Level:
 
 
 class Plan:
-    def __init__(self, engine, N, X, Y, Z, inference=False):
+    def __init__(self, engine, N, X, Y, Z, inference=False, need_input_grad=False):
         net = engine.net
         self.inference = inference        # forward program only: no gradient buffers, no backward program
         self.engine, self.store, self.dt, self.device = engine, engine.store, engine.dt, engine.device
@@ -305,7 +305,9 @@ class Plan:
             raise nat.NativeError("precision='fp16' (IEEE half storage) is implemented for inference: run under torch.no_grad() / "
                                   "the sliding-window inferer, and train with precision='bf16' or 'fp32'")
         self.dims = net.dimensions
-        self.need_input_grad = False
+        # gradient w.r.t. the input image: only the 2-D ``--downsample`` path needs it (a trainable 3->1 convolution sits in front
+        # of the U-Net, capstone/training/base_trainer.py:53,81-85); the stem then gets an input-gradient operand
+        self.need_input_grad = need_input_grad and not inference
         self.packer = Packer(self)
         self.fwd, self.bwd, self._cur = [], [], None
         self._defer = None
@@ -324,7 +326,7 @@ class Plan:
         if not inference:
             self.dlogits = new_act(*self.logits.dims, net.out_channels, self.dt, self.device)
             self._cur = self.bwd
-            self.root.emit_bwd(self.dlogits, need_dx=False)
+            self.dx = self.root.emit_bwd(self.dlogits, need_dx=self.need_input_grad)
         self._cur = None
 
     # ---- recording ----
@@ -556,13 +558,13 @@ class Engine:
             self.store.touch()       # `p.data = ...` keeps the Parameters' version counters: the packed operands are stale anyway
         return self.store
 
-    def plan_for(self, x, inference=False):
+    def plan_for(self, x, inference=False, need_input_grad=False):
         if x.ndim != self.net.dimensions + 2 or x.shape[1] != self.net.in_channels:
             nd = self.net.dimensions
             raise ValueError(f"expected input (B,{self.net.in_channels},{'H,W,D' if nd == 3 else 'H,W'}), got {tuple(x.shape)}")
-        return self.plan_for_shape(x.device, x.shape[0], tuple(x.shape[2:]), inference)
+        return self.plan_for_shape(x.device, x.shape[0], tuple(x.shape[2:]), inference, need_input_grad)
 
-    def plan_for_shape(self, device, N, spatial, inference=False):
+    def plan_for_shape(self, device, N, spatial, inference=False, need_input_grad=False):
         """``inference`` plans hold no backward buffers; an existing training plan of the same shape is reused instead"""
         self.ensure(device)
         nd = self.net.dimensions
@@ -572,25 +574,31 @@ class Engine:
             if v % (2 ** nlev):
                 raise ValueError(f"spatial size {v} is not divisible by 2^{nlev} (the skip concat needs it, as in MONAI)")
         key = (N,) + sp
-        plan = self.plans.get(key) or (self.plans.get(key + ("inference",)) if inference else None)
+        if need_input_grad and not inference:
+            plan = self.plans.get(key + ("dx",))
+            if plan is None:
+                plan = self.plans[key + ("dx",)] = self._record(N, sp, False, True)
+            self.last_plan = plan
+            return plan
+        plan = self.plans.get(key) or self.plans.get(key + ("dx",)) or (self.plans.get(key + ("inference",)) if inference else None)
         if plan is None:
             plan = self.plans[key + (("inference",) if inference else ())] = self._record(N, sp, inference)
         self.last_plan = plan
         return plan
 
-    def _record(self, N, sp, inference):
+    def _record(self, N, sp, inference, need_input_grad=False):
         """record a Plan; bf16 tensors of 9..12 channels (the class logits' neighbours) are laid out 12 wide when every pass
         that touches them can move such rows (ctseg_conv_narrow_ok / ctseg_wgrad_narrow_ok), 16 wide otherwise"""
         from . import engine as eng
         if nat.is16(self.dt) and os.environ.get("CTSEG_NARROW_ROWS", "1") != "0":
             eng.NARROW_ROWS[0] = True
             try:
-                return Plan(self, N, *sp, inference=inference)
+                return Plan(self, N, *sp, inference=inference, need_input_grad=need_input_grad)
             except eng.NarrowUnsupported:
                 pass
             finally:
                 eng.NARROW_ROWS[0] = False
-        return Plan(self, N, *sp, inference=inference)
+        return Plan(self, N, *sp, inference=inference, need_input_grad=need_input_grad)
 
     # ---- raw (no autograd) API used by the native training step, bench and tests ----
     def forward(self, x):
@@ -607,11 +615,9 @@ class Engine:
     # ---- autograd surface (drop-in for loss.backward()) ----
     def forward_autograd(self, x):
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters())
-        plan = self.plan_for(x, inference=not train)
+        plan = self.plan_for(x, inference=not train, need_input_grad=train and x.requires_grad)
         params = self.store.params
         if train:
-            if x.requires_grad:
-                raise NotImplementedError("gradient w.r.t. the input image is not implemented (the reference never needs it)")
             return _UNetFn.apply(x, self, plan, *params)
         plan.forward(x)
         return self.logits_view(plan).clone()
@@ -642,4 +648,10 @@ class _UNetFn(torch.autograd.Function):
         plan.dlogits_is_current = False
         plan.backward()
         grads = [engine.store.grad_view(p).clone() if p.requires_grad else None for p in engine.store.params]
-        return (None, None, None, *grads)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if plan.dx is None:
+                raise RuntimeError("this plan was recorded without an input-gradient pass")
+            gx = plan.dx.valid().float()                       # (B, Cin, X, Y, Z) view of the channels-last gradient
+            gx = (gx[..., 0] if engine.net.dimensions == 2 else gx).contiguous()
+        return (gx, None, None, *grads)

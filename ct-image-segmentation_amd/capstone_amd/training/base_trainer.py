@@ -5,8 +5,10 @@ Row a14 of SURVEY.md §8: the 2-D model is BASELINE.json's configs[0] *plumbing*
 ReduceLROnPlateau(mode="max", factor=0.5, threshold=0.01) monitoring "Mean Dice Score (val)").  A 2-D U-Net is the 3-D
 engine with Z = 1 (9-tap convolutions, 4-class transposed convs); no 2-D-specific kernel exists or is needed.
 
-Not carried over (outside the hot path): the ``--downsample`` 3->1 ``conv1x1`` pre-convolution, the Boundary
-loss (CPU distance maps), mixup and the W&B logger patch.  They raise instead of silently doing something else.
+``--downsample`` (reference :53,81-85: a trainable 3->1 ``conv1x1`` in front of the U-Net) is carried: the channel mix is three
+elementwise multiply-adds on the input image and the engine records an input-gradient pass for the stem when its input requires grad.
+Not carried over (outside the hot path): the Boundary loss (CPU distance maps), mixup and the W&B logger patch.  They
+raise instead of silently doing something else.
 """
 from argparse import ArgumentParser
 from typing import List
@@ -27,8 +29,6 @@ class BaseUNet2D(_Base):
         assert len(filters) == 5, "This module requires a standard 5 block UNet specification"
         assert isinstance(loss_fx, list), "This module expects a list of loss functions"
         loss_fx.sort()
-        if downsample:
-            raise NotImplementedError("--downsample (3->1 conv1x1 pre-convolution) is a 2-D data-pipeline option outside the hot path")
         names = ("batch_size", "transform_degree", "filters", "use_res_units", "downsample", "lr", "loss_fx", "exclude_missing")
         if pl is not None:
             self.save_hyperparameters(*names)
@@ -52,6 +52,12 @@ class BaseUNet2D(_Base):
                     strides=[2, 2, 2, 2], num_res_units=(2 if self.hparams.use_res_units else 0), precision=self._precision)
 
     def forward(self, x):
+        if self.hparams.downsample:
+            # reference :81-85 — a trainable 3 -> 1 channel mix in front of the U-Net.  Three multiply-adds per pixel on the INPUT
+            # image: plain elementwise device ops (not a convolution library call); its gradient comes from the U-Net's input-gradient
+            # pass, which the engine records when the input requires grad
+            w, b = self.conv1x1.weight, self.conv1x1.bias
+            x = (x * w.view(1, -1, 1, 1)).sum(dim=1, keepdim=True) + b.view(1, 1, 1, 1)
         return self.unet(x)
 
     def training_step(self, batch, batch_idx=0):

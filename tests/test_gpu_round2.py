@@ -483,3 +483,35 @@ def test_fused_head_at_full_size_matches_two_pass_loss_and_counts():
     assert torch.equal(out[True][1], out[False][1])
     ga, gb = out[True][2].double(), out[False][2].double()
     assert float(torch.dot(ga, gb) / (ga.norm() * gb.norm())) > 0.999999
+
+
+@pytest.mark.parametrize("nres", [0, 2])
+def test_2d_downsample_conv1x1_trains_on_gpu(nres):
+    """--downsample (capstone/training/base_trainer.py:53,81-85) on the GPU: the trainable 3 -> 1 channel mix in front of the 2-D
+    U-Net gets its gradient from the stem's input-gradient pass (a 4-class stride-2 pass with ONE output column)."""
+    from capstone_amd.training.base_trainer import BaseUNet2D
+    from oracle import losses as OL, metrics as OM
+    from oracle.monai_unet import UNet as OracleUNet
+    torch.manual_seed(11)
+    filters = [8, 16, 24, 32, 48]
+    ref = OracleUNet(2, 1, 10, filters, (2, 2, 2, 2), num_res_units=nres)
+    m = BaseUNet2D(filters=list(filters), use_res_units=nres > 0, downsample=True, loss_fx=["CrossEntropy", "Dice"], transform_degree=1)
+    m.unet.load_state_dict(ref.state_dict())
+    c1 = torch.nn.Conv2d(3, 1, 1)
+    c1.load_state_dict(m.conv1x1.state_dict())
+    m.to(DEV)
+    g = torch.Generator().manual_seed(12)
+    images = torch.randn(2, 3, 64, 96, generator=g)
+    masks = (torch.rand(2, 9, 64, 96, generator=g) < 0.1).to(torch.uint8)
+    ind = torch.ones(2, 9)
+    labels = OM.squash_masks(masks, 10)
+    rv = OL.MultipleLoss(["CrossEntropy", "Dice"])(ref(c1(images)), labels, ind)
+    lref = torch.stack(list(rv.values())).sum()
+    lref.backward()
+    loss = m.training_step((images.to(DEV), masks.to(DEV), ind.to(DEV)))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), lref.item(), rtol=1e-4)
+    gw, gb = m.conv1x1.weight.grad.cpu().numpy(), m.conv1x1.bias.grad.cpu().numpy()
+    np.testing.assert_allclose(gw, c1.weight.grad.numpy(), rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(gb, c1.bias.grad.numpy(), rtol=2e-3, atol=1e-6)
+    assert float(np.abs(c1.weight.grad.numpy()).max()) > 1e-4

@@ -253,3 +253,31 @@ def test_epoch_means_and_overwritten_activation_guard(emu):
     m.training_step(batch)                       # same shape: overwrites the activations l1's graph points at
     with pytest.raises(RuntimeError, match="overwritten"):
         l1.backward()
+
+
+def test_2d_downsample_conv1x1_trains_through_the_input_gradient(emu):
+    """--downsample (capstone/training/base_trainer.py:53,81-85): a trainable 3 -> 1 convolution in front of the 2-D U-Net.  The
+    engine records an input-gradient pass for the stem; conv1x1's weight and bias gradients must equal the oracle's (nn.Conv2d(3,1,1)
+    followed by the oracle U-Net)."""
+    from capstone_amd.training.base_trainer import BaseUNet2D
+    torch.manual_seed(11)
+    filters = [4, 8, 12, 16, 24]
+    ref = OracleUNet(2, 1, 10, filters, (2, 2, 2, 2), num_res_units=2)
+    m = BaseUNet2D(filters=list(filters), use_res_units=True, downsample=True, loss_fx=["CrossEntropy"], transform_degree=1)
+    m.unet.load_state_dict(ref.state_dict())
+    c1 = torch.nn.Conv2d(3, 1, 1)
+    c1.load_state_dict(m.conv1x1.state_dict())
+    g = torch.Generator().manual_seed(12)
+    images = torch.randn(2, 3, 32, 32, generator=g)
+    masks = (torch.rand(2, 9, 32, 32, generator=g) < 0.1).to(torch.uint8)
+    ind = torch.ones(2, 9)
+    labels = OM.squash_masks(masks, 10)
+    lref = OL.MultipleLoss(["CrossEntropy"])(ref(c1(images)), labels, ind)["CrossEntropy"]
+    lref.backward()
+    loss = m.training_step((images, masks, ind))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), lref.item(), rtol=2e-4)
+    np.testing.assert_allclose(m.conv1x1.weight.grad.numpy(), c1.weight.grad.numpy(), rtol=5e-3, atol=1e-6)
+    np.testing.assert_allclose(m.conv1x1.bias.grad.numpy(), c1.bias.grad.numpy(), rtol=5e-3, atol=1e-6)
+    k, p = next(iter(ref.named_parameters()))
+    np.testing.assert_allclose(dict(m.unet.named_parameters())[k].grad.numpy(), p.grad.numpy(), **_tol(k, p.grad.numpy()))
