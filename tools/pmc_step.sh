@@ -8,6 +8,6 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 for grp in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && CTSEG_SIDE_STREAM=0 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$ROOT/$OUT/$grp" -- \
-     python3 "$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 2 > "$ROOT/$OUT/$grp.log" 2>&1)
+     python3 "$ROOT/bench.py" --no-cpu-baseline --fp32-steps 0 --steps 3 --warmup 2 > "$ROOT/$OUT/$grp.log" 2>&1)
 done
 python3 tools/pmc_step_summarise.py "$OUT"
