@@ -481,15 +481,14 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
 
   // ---- fused cross-entropy epilogue ------------------------------------------------------------------------------------------
   float ce_nll = 0.f, ce_w = 0.f;
-  // Dice counters (|pred & true|, |pred|, |true| per class): per LANE, four 8-bit fields per register (class c in word c / 4), one
-  // voxel per lane and tile, flushed before a field can overflow.  (Wave ballots per class put ~100 scalar instructions per tile on
+  // Dice counters (|pred & true|, |pred|, |true| per class): per LANE, two 16-bit fields per register (class c in word c / 2), one
+  // voxel per lane and tile, flushed at every sample change (a field holds 65 535 tiles of one workgroup and sample).  (Wave ballots per class put ~100 scalar instructions per tile on
   // the CU's single scalar unit: 0.36 ms of this launch on a net whose predictions are not yet all background.)
-  uint32_t p_cnt[3][3];
+  uint32_t p_cnt[3][6];
 #pragma unroll
   for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int w = 0; w < 3; ++w) p_cnt[k][w] = 0u;
-  int p_tiles = 0;
+    for (int w = 0; w < 6; ++w) p_cnt[k][w] = 0u;
   unsigned int u_bg = 0u;                  // wave-uniform: voxels of all-background waves (they count for class 0 in all three kinds)
   auto cnt_flush = [&]() {                // per-lane byte fields -> wave sums -> the workgroup's LDS counters
     if (lane == 0 && u_bg != 0u) { atomicAdd(&sCnt[0], u_bg); atomicAdd(&sCnt[16], u_bg); atomicAdd(&sCnt[32], u_bg); }
@@ -498,7 +497,7 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     for (int k = 0; k < 3; ++k)
 #pragma unroll
       for (int c = 0; c < 12; ++c) {
-        unsigned int v = (p_cnt[k][c >> 2] >> ((c & 3) * 8)) & 255u;
+        unsigned int v = (p_cnt[k][c >> 1] >> ((c & 1) * 16)) & 0xffffu;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == 0 && v != 0u) atomicAdd(&sCnt[k * 16 + c], v);
@@ -506,8 +505,7 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int w = 0; w < 3; ++w) p_cnt[k][w] = 0u;
-    p_tiles = 0;
+      for (int w = 0; w < 6; ++w) p_cnt[k][w] = 0u;
   };
   int ce_n = -1;
   auto ce_flush = [&](int n) {            // this workgroup's record of sample n (slot blockIdx.x) and its Dice counts
@@ -629,16 +627,15 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     if (fgb == 0ull) {
       if (!(X_ABL & 32)) u_bg += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(valid));
     } else if (valid) {
-      const uint32_t it = 1u << ((t & 3) * 8), ip = 1u << ((pred & 3) * 8);
-      const int wt = t >> 2, wp = pred >> 2;
+      const uint32_t it = 1u << ((t & 1) * 16), ip = 1u << ((pred & 1) * 16);
+      const int wt = t >> 1, wp = pred >> 1;
 #pragma unroll
-      for (int wq = 0; wq < 3; ++wq) {
+      for (int wq = 0; wq < 6; ++wq) {
         p_cnt[2][wq] += (wt == wq) ? it : 0u;
         p_cnt[1][wq] += (wp == wq) ? ip : 0u;
         p_cnt[0][wq] += (wp == wq && pred == t) ? ip : 0u;
       }
     }
-    if (++p_tiles == 255) cnt_flush();
     const float ce_scale = E.coef[(int64_t)o.n * E.coef_stride] * w;
     float d[12];
 #pragma unroll
