@@ -217,8 +217,17 @@ class _ResUnit:
         if not need_dx:
             return None
         if self.identity:
-            assert not accumulate
-            return g0.emit_dgrad(dy, out=out, add=g)            # dx = g + dgrad(dy)
+            if not accumulate:
+                return g0.emit_dgrad(dy, out=out, add=g)        # dx = g + dgrad(dy)
+            # identity residual AND an accumulated target (a bottom block with equal channel counts under a dense skip gradient):
+            # dx = g + dgrad(dy) into a fresh tensor, then one elementwise pass adds the accumulated term
+            tmp = g0.emit_dgrad(dy, add=g)
+            acc = _addend(out, accumulate)
+            if out is None:
+                out = new_act(*tmp.dims, tmp.C, plan.dt, plan.device)
+            plan.emit("ctseg_instnorm_prelu_fwd", plan.dt, tmp.ptr(), tmp.ld, None, None, acc.ptr(), acc.ld, out.ptr(), out.ld,
+                      tmp.dims[0], tmp.S, tmp.C, keep=(tmp, acc, out))       # mean_rstd = NULL: out = tmp + acc
+            return out
         dx = g0.emit_dgrad(dy, out=out, add=_addend(out, accumulate))
         return self.res_gemm.emit_dgrad(g, out=dx, add=dx)      # += dgrad of the 1x1 residual conv
 

@@ -281,3 +281,24 @@ def test_2d_downsample_conv1x1_trains_through_the_input_gradient(emu):
     np.testing.assert_allclose(m.conv1x1.bias.grad.numpy(), c1.bias.grad.numpy(), rtol=5e-3, atol=1e-6)
     k, p = next(iter(ref.named_parameters()))
     np.testing.assert_allclose(dict(m.unet.named_parameters())[k].grad.numpy(), p.grad.numpy(), **_tol(k, p.grad.numpy()))
+
+
+def test_identity_residual_bottom_under_a_dense_skip_gradient(emu):
+    """equal channel counts at the bottom (ResidualUnit with an identity residual) under the accumulated skip gradient: the
+    input gradient is g + dgrad(dy) PLUS the accumulated term (one extra elementwise pass)."""
+    case = (3, 1, 10, (4, 8, 8), (2, 2), 2, (1, 1, 8, 8, 8))
+    dims, cin, cout, chans, strides, nres, shape = case
+    ref, net = _pair(dims, cin, cout, chans, strides, nres)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(*shape, generator=g)
+    y_ref = ref(x)
+    eng = net.engine()
+    eng.forward(x)
+    np.testing.assert_allclose(eng.logits_view().numpy(), y_ref.detach().numpy(), rtol=2e-4, atol=2e-5)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    pl = eng.last_plan
+    pl.dlogits.t[..., :cout].copy_(gy.permute(0, 2, 3, 4, 1))
+    eng.backward()
+    for (k, p), q in zip(ref.named_parameters(), net.parameters()):
+        np.testing.assert_allclose(eng.store.grad_view(q).numpy(), p.grad.numpy(), err_msg=k, **_tol(k, p.grad.numpy()))
