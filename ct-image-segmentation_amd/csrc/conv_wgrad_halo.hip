@@ -399,6 +399,173 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+// x-column reuse for the transposed operand reads (round 2): a k-step is 32 voxels of ONE x plane (4 y rows x 8 z), so the x^T
+// fragment of output plane p for tap (dx,dy,dz) IS the fragment of halo plane p+1+dx for tap (0,dy,dz).  Eight waves = two k halves
+// (y rows 0-3 / 4-7 of every plane) x four groups of (dy,dz) combos {0,1,2} {3,4} {5,6} {7,8 + the all-ones pseudo tap}: per combo a
+// wave reads the six halo-plane fragments of its half once (12 ds_read_b64_tr_b16) and feeds 12 MFMAs (3 dx x 4 planes) against the
+// four dy fragments of its half — 280 transposed reads per tile instead of 512.  The two k halves accumulate into two slabs.
+template <int NPX, int NPD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_wgrad_head2_kernel(const WgradHaloArgs P, int total_tiles, int x_sample_bytes, int d_sample_bytes) {
+  constexpr int XBYTES = WH_HV * 32, DBYTES = WH_TV * 32, BUF = XBYTES + DBYTES;
+  constexpr int XN = WH_HV * NPX, DN = WH_TV * NPD, JX = (XN + 511) / 512, JD = (DN + 511) / 512;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef s16x4 __attribute__((address_space(3)))* lds_s16x4;
+  __shared__ __attribute__((aligned(16))) char smem[BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int tq = r16 >> 2, tp = r16 & 3;
+  const int YZ = P.Y * P.Z;
+
+  int xo[JX], xl[JX], dof[JD], dl[JD];
+  uint32_t xh[JX], dh[JD];
+#pragma unroll
+  for (int j = 0; j < JX; ++j) {
+    const int idx = tid + j * 512, hv = idx / NPX, part = idx - hv * NPX;
+    const int hx = hv / 100, rem = hv - hx * 100, hy = rem / 10, hz = rem - hy * 10;
+    xo[j] = (hx * YZ + hy * P.Z + hz) * P.g_ld * 2 + part * 8;
+    xh[j] = idx < XN ? ((1u << hx) | (1u << (6 + hy)) | (1u << (16 + hz))) : 0x80000000u;
+    xl[j] = hv * 32 + part * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < JD; ++j) {
+    const int idx = tid + j * 512, tv = idx / NPD, part = idx - tv * NPD;
+    const int tx = tv >> 6, ty = (tv >> 3) & 7, tz = tv & 7;
+    dof[j] = (tx * YZ + ty * P.Z + tz) * P.d_ld * 2 + part * 8;
+    dh[j] = idx < DN ? ((1u << tx) | (1u << (4 + ty)) | (1u << (12 + tz))) : 0x80000000u;
+    dl[j] = XBYTES + tv * 32 + part * 8;
+  }
+  const int bias_bytes = (YZ + P.Z + 1) * P.g_ld * 2;
+  auto range_mask = [](int lo, int hi, int nbits) -> uint32_t {
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > nbits - 1 ? nbits - 1 : hi;
+    return hi < lo ? 0u : ((2u << hi) - (1u << lo));
+  };
+  auto gload = [&](int t, u32x2 (&rx)[JX], u32x2 (&rd)[JD]) {
+    const int n = t / P.tiles;
+    int r = t - n * P.tiles;
+    const int tz = r % P.tzn; r /= P.tzn;
+    const int ty = r % P.tyn, tx = r / P.tyn;
+    const int x0 = tx * 4, y0 = ty * 8, z0 = tz * 8;
+    const uint32_t xm = ~(range_mask(1 - x0, P.X - x0, 6) | (range_mask(1 - y0, P.Y - y0, 10) << 6) | (range_mask(1 - z0, P.Z - z0, 10) << 16));
+    const uint32_t dm = ~(range_mask(0, P.X - x0 - 1, 4) | (range_mask(0, P.Y - y0 - 1, 8) << 4) | (range_mask(0, P.Z - z0 - 1, 8) << 12));
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.in) + (int64_t)n * x_sample_bytes - bias_bytes, 0,
+                                                                         x_sample_bytes + bias_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.dy) + (int64_t)n * d_sample_bytes, 0, d_sample_bytes,
+                                                                         0x00020000);
+    const int xs = ((x0 * P.Y + y0) * P.Z + z0) * P.g_ld * 2, dsf = ((x0 * P.Y + y0) * P.Z + z0) * P.d_ld * 2;
+#pragma unroll
+    for (int j = 0; j < JX; ++j)
+      rx[j] = (WH_ABL & 4) ? u32x2{(uint32_t)xs, 0u} : __builtin_amdgcn_raw_buffer_load_b64(xr, (xh[j] & xm) == 0u ? xo[j] : (int)0x80000000, xs, 0);
+#pragma unroll
+    for (int j = 0; j < JD; ++j)
+      rd[j] = (WH_ABL & 4) ? u32x2{(uint32_t)dsf, 0u} : __builtin_amdgcn_raw_buffer_load_b64(dr, (dh[j] & dm) == 0u ? dof[j] : (int)0x80000000, dsf, 0);
+  };
+  auto sstore = [&](const u32x2 (&rx)[JX], const u32x2 (&rd)[JD]) {
+    if (WH_ABL & 8) { if (rx[0][0] == 0x12345u && rd[0][0] == 0x54321u) smem[tid] = 1; return; }
+#pragma unroll
+    for (int j = 0; j < JX; ++j)
+      if (JX * 512 == XN || tid + j * 512 < XN) *reinterpret_cast<u32x2*>(smem + xl[j]) = rx[j];
+#pragma unroll
+    for (int j = 0; j < JD; ++j)
+      if (JD * 512 == DN || tid + j * 512 < DN) *reinterpret_cast<u32x2*>(smem + dl[j]) = rd[j];
+  };
+
+  const int kh = wave >> 2, cg = wave & 3;               // k half, combo group
+  const int c0 = cg == 0 ? 0 : 2 * cg + 1, nco = cg == 0 ? 3 : 2;      // first (dy,dz) combo of the group, how many
+  f32x4 acc[3][3], acc_ps = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi) acc[ci][dxi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lz = 4 * (q4 & 1) + tq, ly = q4 >> 1;
+  s16x8 ones;
+  {
+    const short o = (r16 == 0) ? (short)0x3f80 : (short)0;
+    ones = s16x8{o, o, o, o, o, o, o, o};
+  }
+  auto tr_frag = [&](const char* p0, int hi_off) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + hi_off));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto compute = [&]() {
+    const char* xs = smem;
+    const char* ds = xs + XBYTES;
+    const int yb = 4 * kh;
+    bf16x8 df[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) df[p] = tr_frag(ds + (((p * 8) + (yb + ly)) * 8 + lz) * 32 + tp * 8, 2 * 8 * 32);
+    const int hb0 = (yb + ly + 1) * 10 + (lz + 1);          // halo voxel of this lane in plane 0, before the (dy,dz) shift
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+      if (ci < nco) {                                        // wave-uniform
+        const int dyz = P.delta[9 + c0 + ci];                // taps 9..17 are the dx = 0 group: delta = dy * 10 + dz
+        bf16x8 xf[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) xf[q] = tr_frag(xs + (q * 100 + hb0 + dyz) * 32 + tp * 8, 2 * 10 * 32);
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[ci][dxi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[p + dxi], df[p], acc[ci][dxi], 0, 0, 0);
+      }
+    }
+    if (cg == 3) {       // pseudo tap 27: row 0 accumulates sum(dy) (bias gradient)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc_ps = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), df[p], acc_ps, 0, 0, 0);
+    }
+  };
+
+  int t = blockIdx.x, tstride = gridDim.x, tlast = total_tiles;
+  if ((gridDim.x & 7) == 0) {
+    const int chunk = (total_tiles + 7) / 8, xcd = blockIdx.x & 7;
+    t = xcd * chunk + (blockIdx.x >> 3);
+    tstride = gridDim.x >> 3;
+    tlast = (xcd + 1) * chunk < total_tiles ? (xcd + 1) * chunk : total_tiles;
+  }
+  // rows narrower than 32 bytes: the pad bytes of every slot are zero for the whole launch
+  if (NPX < 4) for (int i = tid; i < WH_HV; i += 512) *reinterpret_cast<u32x2*>(smem + i * 32 + 24) = u32x2{0u, 0u};
+  if (NPD < 4) for (int i = tid; i < WH_TV; i += 512) *reinterpret_cast<u32x2*>(smem + XBYTES + i * 32 + 24) = u32x2{0u, 0u};
+  // ONE register set of loads in flight per workgroup, FOUR workgroups per CU (128 registers each): the phases of a workgroup
+  // (loads -> multiplies -> barrier -> LDS stores -> barrier) do not overlap inside it; they overlap with the other three's.
+  u32x2 rxA[JX], rdA[JD];
+  if (t < tlast) {
+    gload(t, rxA, rdA);
+    sstore(rxA, rdA);
+  }
+  __syncthreads();
+  for (; t < tlast; t += tstride) {
+    if (t + tstride < tlast) gload(t + tstride, rxA, rdA);
+    compute();
+    __syncthreads();
+    if (t + tstride < tlast) sstore(rxA, rdA);
+    __syncthreads();
+  }
+
+  float* slab = P.ws + ((int64_t)blockIdx.x * 2 + kh) * P.kpad_w * P.cn_pad;       // one slab per k half
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci) {
+    if (ci >= nco) continue;
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi) {
+      const int tap = dxi * 9 + c0 + ci;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = tap * P.Cg + 4 * q4 + e;
+        if (row < P.kpad_w) slab[(int64_t)row * P.cn_pad + r16] = acc[ci][dxi][e];
+      }
+    }
+  }
+  if (cg == 3) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 27 * P.Cg + 4 * q4 + e;
+      if (row < P.kpad_w) slab[(int64_t)row * P.cn_pad + r16] = acc_ps[e];
+    }
+  }
+}
+
 bool wgrad_halo_eligible(const ctseg_wgrad_desc* d) {
   if (d->dtype != CTSEG_BF16 || d->ntaps != 27 || d->sin != 1) return false;
   const int vb = d->Cg * 2, db = ((d->Cn + 15) / 16) * 32;
@@ -418,6 +585,7 @@ bool wgrad_halo_eligible(const ctseg_wgrad_desc* d) {
   return true;
 }
 
+static bool wgrad_head2(const ctseg_wgrad_desc* d);
 static int wgrad_halo_grid(const ctseg_wgrad_desc* d) {
   const int tiles = ((d->Xr + 3) / 4) * ((d->Yr + 7) / 8) * ((d->Zr + 7) / 8) * d->N;
   const int vb = d->Cg * 2, db = ((d->Cn + 15) / 16) * 32;
@@ -425,13 +593,24 @@ static int wgrad_halo_grid(const ctseg_wgrad_desc* d) {
   // per CU for the 32->32 layer); the smaller LDS footprint is kept for what it leaves to the main stream's kernels
   int per_cu = (vb + db <= 64) ? 2 : 1;
   if (vb == 32 && db == 32 && getenv("CTSEG_WGRAD_HEAD_OLD") == nullptr && (d->g_ld == 12 || d->g_ld == 16) && (d->d_ld == 12 || d->d_ld == 16))
-    per_cu = 4;      // conv_wgrad_head_kernel: 27 KB of LDS and 128 registers per workgroup
+    per_cu = wgrad_head2(d) ? 2 : 4;      // 27 KB of LDS, 128 registers: four 4-wave or two 8-wave workgroups per CU
   if (const char* e = getenv("CTSEG_WH_PER_CU")) per_cu = atoi(e);
   int g = 256 * per_cu;
   return g < tiles ? g : tiles;
 }
 
-int wgrad_halo_slabs(const ctseg_wgrad_desc* d) { return wgrad_halo_grid(d); }
+static bool wgrad_head2(const ctseg_wgrad_desc* d) {
+  const int vb = d->Cg * 2, db = ((d->Cn + 15) / 16) * 32;
+  for (int j = 0; j < 27; ++j) {      // the x-column reuse indexes taps as dx * 9 + (dy, dz): canonical order only
+    const int tp = d->taps[j];
+    if ((int)(int8_t)(tp & 0xff) != j / 9 - 1 || (int)(int8_t)((tp >> 8) & 0xff) != (j / 3) % 3 - 1 || (int)(int8_t)((tp >> 16) & 0xff) != j % 3 - 1)
+      return false;
+  }
+  return vb == 32 && db == 32 && getenv("CTSEG_WGRAD_HEAD_OLD") == nullptr && getenv("CTSEG_WGRAD_HEAD_V1") == nullptr &&
+         (d->g_ld == 12 || d->g_ld == 16) && (d->d_ld == 12 || d->d_ld == 16);
+}
+
+int wgrad_halo_slabs(const ctseg_wgrad_desc* d) { return wgrad_head2(d) ? 2 * wgrad_halo_grid(d) : wgrad_halo_grid(d); }
 
 void launch_wgrad_halo(const ctseg_wgrad_desc* d, hipStream_t st) {
   WgradHaloArgs a;
@@ -452,7 +631,12 @@ void launch_wgrad_halo(const ctseg_wgrad_desc* d, hipStream_t st) {
   const int vb = d->Cg * 2, db = ((d->Cn + 15) / 16) * 32;
   if (vb == 32 && db == 32 && getenv("CTSEG_WGRAD_HEAD_OLD") == nullptr && (d->g_ld == 12 || d->g_ld == 16) && (d->d_ld == 12 || d->d_ld == 16)) {
     const int xsb = (int)((int64_t)d->Xi * d->Yi * d->Zi * d->g_ld * 2), dsb = (int)((int64_t)d->Xi * d->Yi * d->Zi * d->d_ld * 2);
-#define WH_GO(NX, ND) hipLaunchKernelGGL((conv_wgrad_head_kernel<NX, ND>), dim3(grid), dim3(256), 0, st, a, total, xsb, dsb)
+    const bool v2 = wgrad_head2(d);
+#define WH_GO(NX, ND)                                                                                                       \
+  do {                                                                                                                      \
+    if (v2) hipLaunchKernelGGL((conv_wgrad_head2_kernel<NX, ND>), dim3(grid), dim3(512), 0, st, a, total, xsb, dsb);         \
+    else hipLaunchKernelGGL((conv_wgrad_head_kernel<NX, ND>), dim3(grid), dim3(256), 0, st, a, total, xsb, dsb);             \
+  } while (0)
     if (d->g_ld == 12) { if (d->d_ld == 12) WH_GO(3, 3); else WH_GO(3, 4); }
     else { if (d->d_ld == 12) WH_GO(4, 3); else WH_GO(4, 4); }
 #undef WH_GO
