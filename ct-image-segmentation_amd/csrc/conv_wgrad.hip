@@ -341,6 +341,9 @@ __global__ __launch_bounds__(32 * NSUB) void wgrad_reduce_kernel(const float* __
   }
 }
 
+bool wgrad_up_eligible(const ctseg_wgrad_desc* d);
+int wgrad_up_slabs(const ctseg_wgrad_desc* d);
+void launch_wgrad_up(const ctseg_wgrad_desc* d, hipStream_t st);
 bool wgrad_stem_eligible(const ctseg_wgrad_desc* d);
 int wgrad_stem_slabs(const ctseg_wgrad_desc* d);
 void launch_wgrad_stem(const ctseg_wgrad_desc* d, hipStream_t st);
@@ -374,6 +377,7 @@ extern "C" int ctseg_wgrad_tile_cols(int32_t Cn) { return Cn <= 16 ? 16 : Cn <= 
 extern "C" int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d) {
   if (d == nullptr) return -1;
   if (wgrad_halo_eligible(d)) return wgrad_halo_slabs(d);
+  if (wgrad_up_eligible(d)) return wgrad_up_slabs(d);
   if (wgrad_stem_eligible(d)) return wgrad_stem_slabs(d);
   return d->N * d->splits;
 }
@@ -395,6 +399,11 @@ extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
     CTSEG_REQUIRE(d->kpad_w >= ktot + 16 && d->cn_pad >= ((d->Cn + 15) / 16) * 16, "conv_wgrad: slab too small for the halo kernel");
     launch_wgrad_halo(d, (hipStream_t)stream);
     CTSEG_LAUNCH_CHECK("conv_wgrad_halo");
+    return 0;
+  }
+  if (wgrad_up_eligible(d)) {
+    launch_wgrad_up(d, (hipStream_t)stream);
+    CTSEG_LAUNCH_CHECK("conv_wgrad_up");
     return 0;
   }
   if (wgrad_stem_eligible(d)) {

@@ -515,3 +515,25 @@ def test_2d_downsample_conv1x1_trains_on_gpu(nres):
     np.testing.assert_allclose(gw, c1.weight.grad.numpy(), rtol=2e-3, atol=1e-6)
     np.testing.assert_allclose(gb, c1.bias.grad.numpy(), rtol=2e-3, atol=1e-6)
     assert float(np.abs(c1.weight.grad.numpy()).max()) > 1e-4
+
+
+@pytest.mark.parametrize("cout,shape", [(10, (2, 5, 6, 9)), (16, (1, 4, 4, 8)), (10, (1, 9, 13, 17)), (12, (3, 1, 2, 3))])
+def test_transposed_conv_weight_gradient_lds_halo_kernel(monkeypatch, cout, shape):
+    """conv_wgrad_up_kernel (ConvTranspose3d 64 -> <= 16, k3 s2; reference layer: MONAI UNet's top up-sampling block behind
+    capstone/models/unet.py) vs torch on the CPU and vs the generic split-K kernel it replaces: ragged tiles on every axis,
+    several samples, extents smaller than one tile."""
+    from capstone_amd._native import BF16
+    from helpers import run_conv_module, rel_err
+    torch.manual_seed(cout + shape[1])
+    mod = torch.nn.ConvTranspose3d(64, cout, 3, 2, 1, output_padding=1)
+    x = torch.randn(shape[0], 64, *shape[1:])
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    _, _, gw, _ = run_conv_module(mod, x, gy, BF16, DEV)
+    assert rel_err(gw, mod.weight.grad) < 2.5e-2
+    monkeypatch.setenv("CTSEG_NO_WGRAD_UP", "1")
+    _, _, gw_generic, _ = run_conv_module(mod, x, gy, BF16, DEV)
+    # same bf16 operands, fp32 accumulation in another order
+    assert rel_err(gw, gw_generic) < 2e-5, rel_err(gw, gw_generic)
