@@ -16,20 +16,36 @@
 // an 8-deep z tile, so there the short tile axis (4 or 2) runs along z and the 8x8 face covers (x, y).
 #include "conv_common.h"
 
+#ifndef SW_ABL
+#define SW_ABL 0     // timing-only ablation: 1 no MFMAs, 2 no LDS operand reads, 4 no weight stream, 8 no output stores (and no addend loads), 16 no halo loads, 32 no addend loads
+#endif
+
 namespace ctseg {
 
-constexpr int SW_NTHR = 512, SW_G = 3, SW_NSTAGE = 9, SW_TAPB = 8192;
+constexpr int SW_NTHR = 512, SW_TAPB = 8192;
 
-template <int VB> struct SwCfg {
-  static constexpr int TA = VB == 128 ? 4 : 2;          // short tile axis
-  static constexpr int HV = (TA + 2) * 100;             // halo slots, (TA+2) x 10 x 10
+// The 128-channel "up" pass (UP, VB = 256) stores only the halo region its taps (offsets 0 / +1) can read — (TA + 1) x 9 rows of 10
+// slots — which lets the 4-deep tile (two row tiles per wave: every weight fragment read from LDS feeds twice the MFMAs, half the
+// weight stream and half the stage barriers per voxel) fit next to a two-tap ring stage: 16 planes x 456 slots + 32 KB = 149 KB.
+// Planes are padded to 8 (mod 16) slots so that the two planes a ds_read_b128 lane group mixes sit on opposite halves of the
+// 256-byte bank row (the 400-slot planes of the 2-deep tile are 0 (mod 16): 2-way conflicts on every operand read).
+template <int VB, bool UP> struct SwCfg {
+  static constexpr bool DENSE = UP && VB == 256;        // halo image holds coordinates 1.. only
+  static constexpr int TA = (VB == 128 || DENSE) ? 4 : 2;          // short tile axis
+  static constexpr int O = DENSE ? 1 : 0;               // first stored halo coordinate
+  static constexpr int LB = 10 - O;                     // stored rows per plane of the short axis
+  static constexpr int HV = DENSE ? 456 : (TA + 2) * 100;   // halo slots per 16-byte channel plane
   static constexpr int NPL = VB / 16, PLANE = HV * 16, HALO = NPL * PLANE;
   static constexpr int CG = VB / 2, CN = SW_TAPB / VB;  // 64 -> 64, 128 -> 32
   static constexpr int NT = CN / 16;
   static constexpr int RT = TA / 2;                     // row tiles (16 voxels) per wave
   static constexpr int KS = CG / 32;                    // 32-wide k-steps per tap
-  static constexpr int WRING = 2 * SW_G * SW_TAPB;
+  static constexpr int G = DENSE ? 2 : 3;               // taps per ring stage
+  static constexpr int NSTAGE = (27 + G - 1) / G;
+  static constexpr int WRING = 2 * G * SW_TAPB;
   static constexpr int TOTAL = HALO + WRING + 8 * 2 * CN * 4 + 128 * 4;
+  static_assert(TOTAL <= 160 * 1024, "LDS");
+  __host__ __device__ static constexpr int slot(int ha, int hb, int hc) { return ((ha - O) * LB + (hb - O)) * 10 + hc; }
 };
 
 struct SwGeom {
@@ -47,8 +63,9 @@ __device__ __forceinline__ void sw_patch_voxel(int r16, int& db, int& c) {
 
 template <typename H, int VB, bool UP, bool STATS>     // H = 16-bit storage kind (BF16 / F16)
 __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P, const SwGeom G, int total_tiles) {
-  using CF = SwCfg<VB>;
+  using CF = SwCfg<VB, UP>;
   constexpr int TA = CF::TA, NPL = CF::NPL, PLANE = CF::PLANE, CN = CF::CN, NT = CF::NT, RT = CF::RT, KS = CF::KS;
+  constexpr int SW_G = CF::G, SW_NSTAGE = CF::NSTAGE;
   constexpr int O = UP ? 1 : 0;                                        // first halo coordinate that is ever read
   constexpr int FA = TA + 2 - O, FB = 10 - O, FV = FA * FB * FB;       // filled region of the halo image
   constexpr int NCH = FV * NPL, J = (NCH + SW_NTHR - 1) / SW_NTHR;
@@ -70,7 +87,7 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
       const int ti = tid - first;
       const int tp = P.cls[c].taps[ti];
       int dv[3] = {(int)(int8_t)(tp & 0xff), (int)(int8_t)((tp >> 8) & 0xff), (int)(int8_t)((tp >> 16) & 0xff)};
-      d = ((dv[G.pa] * 10 + dv[G.pb]) * 10 + dv[G.pc]) * 16;
+      d = ((dv[G.pa] * CF::LB + dv[G.pb]) * 10 + dv[G.pc]) * 16;
       wo = (int)(P.cls[c].w_off + (int64_t)ti * CF::CG);
       kp = P.cls[c].kpad;
       cl = c | ((ti == P.cls[c].ntaps - 1) ? 256 : 0);
@@ -88,7 +105,7 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
     const int ha = fa + O, hb = fb + O, hc = fc + O;                   // halo coordinates, tile origin = (1,1,1)
     g_byte[j] = (((ha - 1) * G.ia + (hb - 1) * G.ib + (hc - 1) * G.ic) * P.g_ld + pl * 8) * 2;
     g_habc[j] = (fv < FV) ? (ha | (hb << 8) | (hc << 16)) : 0x7f7f7f;  // sentinel fails every bounds test
-    g_lds[j] = pl * PLANE + ((ha * 10 + hb) * 10 + hc) * 16;
+    g_lds[j] = pl * PLANE + CF::slot(ha, hb, hc) * 16;
   }
   auto tile_origin = [&](int t, int& n, int& a0, int& b0, int& c0) {
     n = t / G.tiles;
@@ -107,7 +124,7 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
     for (int j = 0; j < J; ++j) {
       const int ai = a0 - 1 + (g_habc[j] & 0xff), bi = b0 - 1 + ((g_habc[j] >> 8) & 0xff), ci = c0 - 1 + (g_habc[j] >> 16);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if ((unsigned)ai < (unsigned)G.da && (unsigned)bi < (unsigned)G.db && (unsigned)ci < (unsigned)G.dc)
+      if (!(SW_ABL & 16) && (unsigned)ai < (unsigned)G.da && (unsigned)bi < (unsigned)G.db && (unsigned)ci < (unsigned)G.dc)
         v = *reinterpret_cast<const u32x4*>(base + g_byte[j]);
       rh[j] = v;
     }
@@ -129,6 +146,8 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
 #pragma unroll
     for (int g = 0; g < SW_G; ++g) {
       const int tap = stage_in_tile * SW_G + g;
+      if (SW_G * SW_NSTAGE > 27 && tap >= 27) continue;      // the last stage of the two-tap ring holds one tap
+      if (SW_ABL & 4) continue;
       const char* src = P.w + ((int64_t)sTab[32 + tap] + (int64_t)w_row * sTab[64 + tap] + w_koff) * 2;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + g * SW_TAPB), 16, 0, 0);
     }
@@ -145,7 +164,7 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
     const int i = (TA == 4) ? (2 * (wave & 1) + rt) : (wave & 3);
     va[rt] = wa;
     vb[rt] = 2 * i + pdb;
-    abase[rt] = (((wa + 1) * 10 + (vb[rt] + 1)) * 10 + (pc + 1)) * 16 + q4 * PLANE;
+    abase[rt] = CF::slot(wa + 1, vb[rt] + 1, pc + 1) * 16 + q4 * PLANE;
   }
   const int wrd = r16 * 128, wswz = (r16 >> 1) & 7;
   const bool af32 = P.add_f32 != 0;
@@ -197,8 +216,99 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  // epilogue of one class straight from the accumulators: lane = (voxel of row tile rt, channels j*16 + 4*q4 .. +3)
-  auto epilogue = [&](int cls, int n, int a0, int b0, int c0) {
+  // Epilogue of one class straight from the accumulators: lane = (voxel of row tile rt, channels j*16 + 4*q4 .. +3).
+  // Stores and addend loads are raw buffer operations with a per-sample descriptor: lanes outside the volume get an out-of-range
+  // offset, so every wave issues the SAME number of vector-memory operations per epilogue and the stage barrier can wait for the
+  // weight DMA alone (s_waitcnt vmcnt(<operations issued after it>)) instead of draining the stores it has just issued.  The bf16 /
+  // fp16 addend of the NEXT class is requested in the epilogue of the current one (of the first class: at the top of the tile) and
+  // has a whole class of multiplies to arrive.
+  const int out_sample_bytes = (int)(out_sample * P.o_ld * 2), add_sample_bytes = (int)(out_sample * P.add_ld * ASZ);
+  const bool apf = UP && !STATS && P.add != nullptr && !af32;    // prefetched 16-bit addend (the statistics variants have no registers to spare)
+  int ooff[RT], aoff[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int vox = va[rt] * G.oa + vb[rt] * G.ob + pc * G.oc;
+    ooff[rt] = (vox * P.o_ld + 4 * q4) * 2;
+    aoff[rt] = (vox * P.add_ld + 4 * q4) * ASZ;
+  }
+  u32x2 apre[RT][NT];
+  int pend = 0;                                         // vector-memory operations issued since this stage's weight DMA (wave-uniform)
+  auto class_base = [&](int cls, int a0, int b0, int c0) -> int {
+    const ctseg_conv_class& K = P.cls[cls];
+    return a0 * G.oa + b0 * G.ob + c0 * G.oc + (K.ox * P.Yo + K.oy) * P.Zo + K.oz;
+  };
+  auto add_issue = [&](int cls, int n, int a0, int b0, int c0) {        // cls < 0: nothing to fetch (same operation count)
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.add) + (int64_t)n * add_sample_bytes, 0, add_sample_bytes, 0x00020000);
+    const int soff = cls >= 0 ? class_base(cls, a0, b0, c0) * P.add_ld * ASZ : 0;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool rv = cls >= 0 && (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        apre[rt][j] = (SW_ABL & 32) ? u32x2{0u, 0u} : __builtin_amdgcn_raw_buffer_load_b64(ars, rv ? aoff[rt] + j * 16 * ASZ : (int)0x80000000, soff, 0);
+    }
+    pend += RT * NT;
+  };
+  auto epilogue = [&](int cls, int next_cls, int n, int a0, int b0, int c0) {
+    const int cb = class_base(cls, a0, b0, c0);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(P.out + (int64_t)n * out_sample_bytes, 0, out_sample_bytes, 0x00020000);
+    const int soff = cb * P.o_ld * 2;
+    // 16-byte stores: v_permlane16_swap hands the lanes of q4 = 0 / 2 the neighbouring 4 channels of their own 16-column block and the
+    // lanes of q4 = 1 / 3 those of the next block, so a lane holds 8 consecutive channels (16-byte chunk {0, 2, 1, 3}[q4] of 32 channels)
+    const int cbq = ((q4 & 1) * 2 + (q4 >> 1)) * 16;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool rv = (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
+      u32x2 o2[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[rt][j][e] + bias[j][e];
+          if (STATS && rv) { wsum[j][e] += v[e]; wsq[j][e] += v[e] * v[e]; }
+        }
+        if (apf) {
+          const u32x2 w2 = apre[rt][j];
+          v[0] += h2f<H>(w2[0] & 0xffffu); v[1] += h2f<H>(w2[0] >> 16); v[2] += h2f<H>(w2[1] & 0xffffu); v[3] += h2f<H>(w2[1] >> 16);
+        } else if (P.add != nullptr && rv) {      // fp32 addend, or a statistics pass with an addend: fetched here
+          const char* ap = P.add + (int64_t)n * add_sample_bytes + (int64_t)cb * P.add_ld * ASZ + aoff[rt] + j * 16 * ASZ;
+          if (af32) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap); v[0] += a4[0]; v[1] += a4[1]; v[2] += a4[2]; v[3] += a4[3]; }
+          else {
+            const u32x2 w2 = *reinterpret_cast<const u32x2*>(ap);
+            v[0] += h2f<H>(w2[0] & 0xffffu); v[1] += h2f<H>(w2[0] >> 16); v[2] += h2f<H>(w2[1] & 0xffffu); v[3] += h2f<H>(w2[1] >> 16);
+          }
+        }
+        o2[j] = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
+      }
+#pragma unroll
+      for (int jp = 0; jp < NT / 2; ++jp) {
+        const auto s0 = __builtin_amdgcn_permlane16_swap(o2[2 * jp][0], o2[2 * jp + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(o2[2 * jp][1], o2[2 * jp + 1][1], false, false);
+        const u32x4 o4 = {s0[0], s1[0], s0[1], s1[1]};
+        const bool keep = rv && (!(SW_ABL & 8) || o4[0] == 0x12345u);
+        __builtin_amdgcn_raw_buffer_store_b128(o4, ors, keep ? ooff[rt] - 4 * q4 * 2 + jp * 64 + cbq : (int)0x80000000, soff, 0);
+      }
+    }
+    pend += RT * NT / 2;
+    if (apf) add_issue(next_cls, n, a0, b0, c0);
+  };
+  // stage barrier: the next stage's weight DMA (issued first in this stage) has landed, later stores / addend loads may still fly
+  auto stage_barrier = [&]() {
+    constexpr int E1 = RT * NT / 2, E2 = RT * NT / 2 + RT * NT;      // one epilogue without / with the next addend request
+    if (pend == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (pend == E1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(E1) : "memory");
+    else if (pend == 2 * E1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * E1) : "memory");
+    else if (pend == E2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(E2) : "memory");
+    else if (pend == 2 * E2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * E2) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    pend = 0;
+  };
+
+  // single-class passes (one epilogue per tile): plain global stores, addend fetched in place.  lane: lane = (voxel of row tile rt, channels j*16 + 4*q4 .. +3)
+  auto epilogue_plain = [&](int cls, int n, int a0, int b0, int c0) {
     const ctseg_conv_class& K = P.cls[cls];
     int ov[3] = {K.ox, K.oy, K.oz};
     const int64_t obase = n * out_sample + (int64_t)a0 * G.oa + (int64_t)b0 * G.ob + (int64_t)c0 * G.oc +
@@ -266,36 +376,43 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
       if (s + 1 < SW_NSTAGE) wload(s + 1, slot ^ 1);
       else if (tn < last) wload(0, slot ^ 1);        // first stage of the next tile
       if (s == 0 && tn < last) gload(tn);            // next halo rides in registers until this tile is done
+      if (apf && s == 0) add_issue(sTab[96] & 255, n, a0, b0, c0);
       const char* wb = sW + slot * (SW_G * SW_TAPB) + wrd;
 #pragma unroll
       for (int g = 0; g < SW_G; ++g) {
         const int tap = s * SW_G + g;
+        if (SW_G * SW_NSTAGE > 27 && tap >= 27) continue;
         const int delta = sTab[tap];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           u32x4 xf[RT], wf[NT];
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) xf[rt] = *reinterpret_cast<const u32x4*>(sH + abase[rt] + ks * 4 * PLANE + delta);
+          for (int rt = 0; rt < RT; ++rt)
+            xf[rt] = (SW_ABL & 2) ? u32x4{(uint32_t)(delta + rt), 1u, 2u, (uint32_t)ks} : *reinterpret_cast<const u32x4*>(sH + abase[rt] + ks * 4 * PLANE + delta);
           const char* wk = wb + g * SW_TAPB + (ks >> 1) * (CN * 128) + (((4 * (ks & 1) + q4) ^ wswz) << 4);
 #pragma unroll
-          for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4*>(wk + j * 16 * 128);
+          for (int j = 0; j < NT; ++j) wf[j] = (SW_ABL & 2) ? u32x4{(uint32_t)(j + g), 3u, (uint32_t)tap, 5u} : *reinterpret_cast<const u32x4*>(wk + j * 16 * 128);
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) mma16<H>(acc[rt][j], wf[j], xf[rt]);
+            for (int j = 0; j < NT; ++j) {
+              if constexpr ((SW_ABL & 1) != 0) acc[rt][j][0] += __builtin_bit_cast(f32x4, wf[j])[0] * __builtin_bit_cast(f32x4, xf[rt])[1];
+              else mma16<H>(acc[rt][j], wf[j], xf[rt]);
+            }
         }
         if constexpr (UP) {
           const int cl = sTab[96 + tap];
           if (cl & 256) {                            // wave-uniform: last tap of a parity class
-            epilogue(cl & 255, n, a0, b0, c0);
+            epilogue(cl & 255, tap + 1 < 27 ? (sTab[96 + tap + 1] & 255) : -1, n, a0, b0, c0);
             zero_acc();
           }
         }
       }
       ++wstage;
-      __syncthreads();                               // next stage's DMA landed (vmcnt(0) before the barrier), this slot is free
+      if constexpr (UP) stage_barrier();             // next stage's DMA landed, this slot is free
+      else __syncthreads();
     }
-    if constexpr (!UP) epilogue(0, n, a0, b0, c0);
+    if constexpr (!UP) epilogue_plain(0, n, a0, b0, c0);
     if (tn < last) {
       // every wave passed the last stage barrier => nobody reads the halo any more
       sstore();
@@ -307,7 +424,7 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 static bool sw_geom(const ConvKArgs& a, int vb, SwGeom& g) {
-  const int ta = vb == 128 ? 4 : 2;
+  const int ta = (vb == 128 || a.sout == 2) ? 4 : 2;      // SwCfg<VB, UP>::TA
   const int dims[3] = {a.Xr, a.Yr, a.Zr};
   const int istr[3] = {a.Yi * a.Zi, a.Zi, 1};
   const int ostr[3] = {a.Yo * a.Zo * a.sout, a.Zo * a.sout, a.sout};
