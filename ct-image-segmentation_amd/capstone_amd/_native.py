@@ -58,7 +58,8 @@ class ConvDesc(C.Structure):
                 ("sin", C.c_int32), ("sout", C.c_int32), ("out_f32", C.c_int32), ("add_f32", C.c_int32),
                 ("stats_ld", C.c_int32), ("stats_tiles", C.c_int32), ("stats_tile0", C.c_int32),
                 ("nclass", C.c_int32), ("cls", ConvClass * MAX_CLASSES),
-                ("out2", C.c_void_p), ("out2_col0", C.c_int32), ("o2_ld", C.c_int32)]
+                ("out2", C.c_void_p), ("out2_col0", C.c_int32), ("o2_ld", C.c_int32),
+                ("in_mean_rstd", C.c_void_p), ("in_alpha", C.c_void_p), ("in_norm_C", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -67,7 +68,8 @@ class WgradDesc(C.Structure):
                 ("Xr", C.c_int32), ("Yr", C.c_int32), ("Zr", C.c_int32),
                 ("Cg", C.c_int32), ("Cn", C.c_int32), ("g_ld", C.c_int32), ("d_ld", C.c_int32), ("sin", C.c_int32),
                 ("ntaps", C.c_int32), ("taps", C.c_int32 * MAX_TAPS), ("splits", C.c_int32),
-                ("kpad_w", C.c_int32), ("cn_pad", C.c_int32)]
+                ("kpad_w", C.c_int32), ("cn_pad", C.c_int32),
+                ("in_mean_rstd", C.c_void_p), ("in_alpha", C.c_void_p), ("in_norm_C", C.c_int32)]
 
 
 _i32, _i64, _f32, _f64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
@@ -80,6 +82,8 @@ _SIGS = {
     "ctseg_conv_split_ok": (C.c_int, [C.POINTER(ConvDesc)]),
     "ctseg_conv_narrow_ok": (C.c_int, [C.POINTER(ConvDesc)]),
     "ctseg_wgrad_narrow_ok": (C.c_int, [C.POINTER(WgradDesc)]),
+    "ctseg_conv_in_norm_ok": (C.c_int, [C.POINTER(ConvDesc)]),
+    "ctseg_wgrad_in_norm_ok": (C.c_int, [C.POINTER(WgradDesc)]),
     "ctseg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "ctseg_wgrad_tile_cols": (C.c_int, [_i32]),
     "ctseg_conv_wgrad_slabs": (C.c_int, [C.POINTER(WgradDesc)]),

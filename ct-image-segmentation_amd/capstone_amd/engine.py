@@ -32,10 +32,11 @@ def rup(a, b):
 
 class Act:
     """Channels-last activation handle: tensor [N,X,Y,Z,ld], C valid channels starting at c0."""
-    __slots__ = ("t", "C", "c0", "dt")
+    __slots__ = ("t", "C", "c0", "dt", "pending_norm")
 
     def __init__(self, t, C, c0=0, dt=None):
         self.t, self.C, self.c0 = t, C, c0
+        self.pending_norm = None      # a _NormAct whose InstanceNorm + PReLU the consumers of this raw conv output apply on load
         self.dt = dt if dt is not None else {torch.float32: F32, torch.float16: nat.F16}.get(t.dtype, BF16)
 
     @property
@@ -352,7 +353,22 @@ class GemmLayer:
             rowgrid, sin, sout = od[1:], (1 if self.transposed else self.s), 1
         stats = None
         bias_ptr = plan.packer.bias_ptr(self.bias_off)
+        pend = getattr(x, "pending_norm", None)
+        if pend is not None and os.environ.get("CTSEG_NORM_ON_LOAD", "1") == "0":
+            x = pend.materialise(x)
+            add = x if add is not None and getattr(add, "pending_norm", None) is pend else add
+            pend = None
         d = self._desc(self.fwd_pack, self.fwd_classes, x, out, rowgrid, sin, sout, self.Cn, self.cg, bias_ptr, add, None, out_f32)
+        if pend is not None:
+            # the producing layer's InstanceNorm + PReLU is applied to the operand on its way into this pass (the activation is
+            # never written) where the kernel taking the pass can; otherwise the apply pass is recorded now
+            assert add is None or add is x, "a deferred norm feeds the pass and (optionally) its identity residual only"
+            d.in_mean_rstd, d.in_alpha, d.in_norm_C = pend.mr.data_ptr(), plan.store.p_ptr(pend.alpha), x.C
+            if nat.query("ctseg_conv_in_norm_ok", d) != 1:
+                xm = pend.materialise(x)
+                d = self._desc(self.fwd_pack, self.fwd_classes, xm, out, rowgrid, sin, sout, self.Cn, self.cg, bias_ptr,
+                               xm if add is not None else None, None, out_f32)
+                x, add = xm, (xm if add is not None else None)
         if want_stats:
             tiles = nat.lib().ctseg_conv_num_tiles(d)
             assert tiles > 0
@@ -422,6 +438,15 @@ class GemmLayer:
         for j, (_, off) in enumerate(self.wg_taps):
             d.taps[j] = off
         d.splits, d.kpad_w, d.cn_pad = splits, kpad_w, cn_pad
+        pend = getattr(gathered, "pending_norm", None)
+        if pend is not None:
+            assert not self.transposed
+            d.in_mean_rstd, d.in_alpha, d.in_norm_C = pend.mr.data_ptr(), st.p_ptr(pend.alpha), gathered.C
+            if os.environ.get("CTSEG_NORM_ON_LOAD", "1") == "0" or nat.query("ctseg_wgrad_in_norm_ok", d) != 1:
+                gathered = pend.materialise(gathered)
+                d.in_mean_rstd = d.in_alpha = None
+                d.in_norm_C = 0
+                d.in_, d.g_ld = gathered.ptr(), gathered.ld
         if plan.dt == BF16 and (gathered.ld == 12 or dyy.ld == 12) and nat.query("ctseg_wgrad_narrow_ok", d) != 1:
             raise NarrowUnsupported(self.name + " (weight gradient)")
         nslabs = lib.ctseg_conv_wgrad_slabs(d)     # N*splits, or one per persistent workgroup (LDS-halo kernel)

@@ -40,6 +40,24 @@ class _NormAct:
     def __init__(self, plan, alpha):
         self.plan, self.alpha = plan, alpha
 
+    def defer(self, y, stats):
+        """statistics only: the apply pass is left to the consumers of ``y`` (operand normalisation on load,
+        ctseg_conv_desc::in_mean_rstd); ``materialise`` records it for a consumer that cannot"""
+        self.y = y
+        self.mr = stats.emit_finalize(0, y.C)
+        self._applied = None
+        y.pending_norm = self
+        return y
+
+    def materialise(self, y):
+        if self._applied is None:
+            plan = self.plan
+            out = new_act(*y.dims, y.C, plan.dt, plan.device)
+            plan.emit("ctseg_instnorm_prelu_fwd", plan.dt, y.ptr(), y.ld, self.mr.data_ptr(), plan.store.p_ptr(self.alpha),
+                      None, 0, out.ptr(), out.ld, y.dims[0], y.S, y.C, keep=(y, out))
+            self._applied = out
+        return self._applied
+
     def emit_fwd(self, y, stats, col0, res, out):
         plan = self.plan
         self.y = y
@@ -94,12 +112,14 @@ class _ConvBlock:
         self.na = None if mod.conv_only else _NormAct(plan, mod.act.weight)
         self.params = [mod.conv.weight, mod.conv.bias] + ([] if mod.conv_only else [mod.act.weight])
 
-    def emit_fwd(self, x, out=None, out_f32=False):
+    def emit_fwd(self, x, out=None, out_f32=False, defer_norm=False):
         self.x = x
         if self.na is None:
             y, _ = self.gemm.emit_fwd(x, out=out, out_f32=out_f32)
             return y
         y, stats = self.gemm.emit_fwd(x, want_stats=True)
+        if defer_norm and out is None:
+            return self.na.defer(y, stats)
         return self.na.emit_fwd(y, stats, 0, None, out)
 
     def emit_bwd(self, g, out=None, accumulate=False, need_dx=True, split_at=None):
@@ -269,7 +289,10 @@ class _Level:
         self.sub.emit_fwd(xd, out=self.cat.slice(self.c1, self.c2))
         if self.up1 is None:
             return self.up0.emit_fwd(self.cat, out=out, out_f32=out_f32)
-        a = self.up0.emit_fwd(self.cat)
+        # the head (identity-residual unit whose only consumer of the activation is one 3x3x3 conv, its residual and its weight
+        # gradient): the transposed conv's InstanceNorm + PReLU is applied by those passes on load, the activation is not written
+        head = self.is_top and self.up1.identity and len(self.up1.units) == 1 and self.up1.nas[0] is None and nat.is16(plan.dt)
+        a = self.up0.emit_fwd(self.cat, defer_norm=head)
         return self.up1.emit_fwd(a, out=out, out_f32=out_f32)
 
     def emit_bwd(self, g, out=None, accumulate=False, need_dx=True, depth=0):

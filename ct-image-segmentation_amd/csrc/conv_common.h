@@ -23,6 +23,10 @@ struct ConvKArgs {
   int out2_col0, o2_ld;
   int dtype;       // CTSEG_F32 / CTSEG_BF16 / CTSEG_F16 storage of the pass (the launchers pick the instantiation from it)
   int xcd_order;   // generic / ring kernels: grid.x = 8 * ceil(tiles*N / 8), workgroup L takes tile (L&7)*chunk + (L>>3)
+  // InstanceNorm + PReLU of the gathered operand on load (ctseg_conv_desc::in_mean_rstd): x-column halo pass over 12-wide rows only
+  const float* in_mr;
+  const float* in_alpha;
+  int in_C;
 };
 
 // Workgroups reach the 8 XCDs round-robin by linear id.  Tile = (L & 7) * chunk + (L >> 3) gives every XCD one contiguous
@@ -200,6 +204,7 @@ bool conv_stem_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_stem_slots(const ConvKArgs& a);
 void launch_conv_stem(ConvKArgs& a, hipStream_t st);
 // conv_halo_sw.hip: LDS halo + streamed weights, Cg=64->Cn=64 (one class) and Cg=128->Cn=32 (8 parity classes), bf16
+bool conv_halo_x_in_norm_ok(const ConvKArgs& a, int dtype, int nclass);
 bool conv_halo_sw_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_halo_sw_slots(const ConvKArgs& a);
 void launch_conv_halo_sw(ConvKArgs& a, int nclass, hipStream_t st);

@@ -16,6 +16,12 @@
 // an 8-deep z tile, so there the short tile axis (4 or 2) runs along z and the 8x8 face covers (x, y).
 #include "conv_common.h"
 
+#ifndef SW_STORE8
+#define SW_STORE8 0
+#endif
+#ifndef SW_FULL_WAIT
+#define SW_FULL_WAIT 0
+#endif
 #ifndef SW_ABL
 #define SW_ABL 0     // timing-only ablation: 1 no MFMAs, 2 no LDS operand reads, 4 no weight stream, 8 no output stores (and no addend loads), 16 no halo loads, 32 no addend loads
 #endif
@@ -281,6 +287,12 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
         }
         o2[j] = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
       }
+#if SW_STORE8
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        __builtin_amdgcn_raw_buffer_store_b64(o2[j], ors, rv ? ooff[rt] + j * 32 : (int)0x80000000, soff, 0);
+      continue;
+#endif
 #pragma unroll
       for (int jp = 0; jp < NT / 2; ++jp) {
         const auto s0 = __builtin_amdgcn_permlane16_swap(o2[2 * jp][0], o2[2 * jp + 1][0], false, false);
@@ -288,6 +300,11 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
         const u32x4 o4 = {s0[0], s1[0], s0[1], s1[1]};
         const bool keep = rv && (!(SW_ABL & 8) || o4[0] == 0x12345u);
         __builtin_amdgcn_raw_buffer_store_b128(o4, ors, keep ? ooff[rt] - 4 * q4 * 2 + jp * 64 + cbq : (int)0x80000000, soff, 0);
+        // The data registers of a 16-byte buffer store must not be rewritten in the next two issue slots (the ">64-bit store data"
+        // hazard): the compiler does not pad it when the store has an SGPR offset, and in the statistics variant it scheduled a
+        // v_mov into the first data register right behind the store — a few 16-bit elements per launch came out as garbage.
+        // Keeping the registers live across two wait states closes the window.
+        asm volatile("s_nop 1" ::"v"(o4));
       }
     }
     pend += RT * NT / 2;
@@ -296,7 +313,7 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
   // stage barrier: the next stage's weight DMA (issued first in this stage) has landed, later stores / addend loads may still fly
   auto stage_barrier = [&]() {
     constexpr int E1 = RT * NT / 2, E2 = RT * NT / 2 + RT * NT;      // one epilogue without / with the next addend request
-    if (pend == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (SW_FULL_WAIT || pend == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else if (pend == E1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(E1) : "memory");
     else if (pend == 2 * E1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * E1) : "memory");
     else if (pend == E2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(E2) : "memory");

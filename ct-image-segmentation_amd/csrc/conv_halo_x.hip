@@ -27,6 +27,7 @@
 namespace ctseg {
 
 constexpr int X_TX = 4, X_TY = 8, X_TZ = 8;
+constexpr int X_NRM_MAXN = 16;      // samples whose operand-normalisation constants fit the LDS table
 constexpr int X_HX = X_TX + 2, X_HY = X_TY + 2, X_HZ = X_TZ + 2, X_HV = X_HX * X_HY * X_HZ;   // 600 halo voxels
 constexpr int X_PIECES = (X_HV + 63) / 64;                                                     // 10 DMA pieces per plane
 // plane stride in 16-byte slots: >= 64 * X_PIECES (a DMA piece writes 64 slots) and = 8 (mod 16), so that the two planes an
@@ -123,8 +124,10 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
   static_assert(ADD != 3 || APIECES % NW == 0, "every wave issues the same number of addend pieces");
   constexpr int CE_T = CE ? NW * 2 * 16 * 48 : 0;           // per-wave exchange scratch: 12 fp32 logits per voxel, two x planes at a time
   constexpr int CE_B = CE ? 3 * 16 * 4 + NW * 2 * 8 : 0;     // Dice counters, per-wave loss sums
-  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B + 2 * ABUF];
+  constexpr int NRM_B = R12 ? X_NRM_MAXN * 96 : 0;           // operand normalisation: per sample 3 channel quads x (mean x 4, rstd x 4)
+  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B + 2 * ABUF + NRM_B];
   char* const sA = smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B;
+  float* const sPar = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B + 2 * ABUF);
   char* const sW = smem + 2 * CF::HALO;
   float* const sStats = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES);     // per-wave statistics slots
   char* const sT = smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4;
@@ -337,11 +340,47 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
       rg[j] = (X_ABL & 4) ? u32x2{0u, 0u} : __builtin_amdgcn_raw_buffer_load_b64(rs, vo, soff, 0);
     }
   };
-  auto sstore = [&](int buf) {
-    char* dst = smem + buf * CF::HALO;
+  // Operand normalisation on load (ctseg_conv_desc::in_mean_rstd): the staged 8-byte piece (4 channels of one voxel) becomes
+  // prelu((x - mean) * rstd) — the arithmetic of instnorm_prelu_fwd_kernel, rounded to the storage type as that pass rounds its
+  // output — before it is written to LDS; voxels outside the volume (zero padding of the ACTIVATION) and channels >= in_C stay 0.
+  // Piece j of this thread holds channel quad (tid + j) % 3: three table addresses, rotated.
+  const bool nrm = R12 && P.in_mr != nullptr;
+  const float nrm_al = nrm ? P.in_alpha[0] : 1.f;
+  int prot[3] = {0, 0, 0};
+  if constexpr (R12) {
+    if (nrm) {
+      for (int i = tid; i < P.N * 24; i += NTHR) {
+        const int n = i / 24, k = i - n * 24, c = (k >> 3) * 4 + (k & 3);
+        sPar[i] = c < P.in_C ? P.in_mr[((int64_t)n * P.in_C + c) * 2 + ((k >> 2) & 1)] : 0.f;     // rstd = 0 keeps pad channels at 0
+      }
 #pragma unroll
-    for (int j = 0; j < R_J; ++j)
-      if (R_J * NTHR == R_N || tid + j * NTHR < R_N) *reinterpret_cast<u32x2*>(dst + rlds[j]) = rg[j];
+      for (int k = 0; k < 3; ++k) prot[k] = ((tid + k) % 3) * 8;
+    }
+  }
+  auto sstore = [&](int buf, const Org& o) {
+    char* dst = smem + buf * CF::HALO;
+    if (!nrm) {
+#pragma unroll
+      for (int j = 0; j < R_J; ++j)
+        if (R_J * NTHR == R_N || tid + j * NTHR < R_N) *reinterpret_cast<u32x2*>(dst + rlds[j]) = rg[j];
+      return;
+    }
+    const uint32_t notm = ~(range_mask(1 - o.x0, P.Xi - o.x0, X_HX) | (range_mask(1 - o.y0, P.Yi - o.y0, X_HY) << 6) |
+                            (range_mask(1 - o.z0, P.Zi - o.z0, X_HZ) << 16));
+    const float* par = sPar + o.n * 24;
+#pragma unroll
+    for (int j = 0; j < R_J; ++j) {
+      const f32x4 mean = *reinterpret_cast<const f32x4*>(par + prot[j % 3]), rstd = *reinterpret_cast<const f32x4*>(par + prot[j % 3] + 4);
+      float v[4] = {h2f<H>(rg[j][0] & 0xffffu), h2f<H>(rg[j][0] >> 16), h2f<H>(rg[j][1] & 0xffffu), h2f<H>(rg[j][1] >> 16)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = (v[e] - mean[e]) * rstd[e];
+        v[e] = a > 0.f ? a : nrm_al * a;
+      }
+      const bool inside = (rhot[j] & notm) == 0u;
+      const u32x2 w = inside ? u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])} : u32x2{0u, 0u};
+      if (R_J * NTHR == R_N || tid + j * NTHR < R_N) *reinterpret_cast<u32x2*>(dst + rlds[j]) = w;
+    }
   };
 
   // ---- epilogue of one tile, in a head (per-tile scalars, addend loads) and X_TX slices (one x plane each) so that the slices
@@ -407,8 +446,11 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
       }
       const int vo = (ok && ch_ok[j] && !(X_ABL & 2)) ? ooff + 16 * j * OSZ : (int)0x80000000;
       if constexpr (OF32) {
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
-                                               e.ors, vo, e.sbase + i * oplane, 0);
+        const u32x4 o4 = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(o4, e.ors, vo, e.sbase + i * oplane, 0);
+        // >64-bit store data hazard: the compiler does not pad it for a buffer store with an SGPR offset (conv_halo_sw.hip's class
+        // epilogue lost 16-bit elements to a v_mov scheduled right behind such a store); keep the data registers live for two wait states
+        asm volatile("s_nop 1" ::"v"(o4));
       } else {
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])}, e.ors, vo, e.sbase + i * oplane, 0);
       }
@@ -685,8 +727,9 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     if constexpr (R12) {
       for (int i = tid; i < 2 * X_HVP; i += NTHR)
         *reinterpret_cast<u32x2*>(smem + (i / X_HVP) * CF::HALO + X_PLANE + (i % X_HVP) * 16 + 8) = u32x2{0u, 0u};
+      __syncthreads();       // the operand-normalisation table is written
       gload(ocur);
-      sstore(0);
+      sstore(0, ocur);
     } else {
       dma(ocur, 0);
     }
@@ -703,7 +746,7 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
       }
       compute_tile(F_{}, buf, accA, caddA, ep, accA, caddA);
       ce_epilogue(ocur, accA, caddA, lab_cur);
-      if constexpr (R12) { if (more) sstore(buf ^ 1); }
+      if constexpr (R12) { if (more) sstore(buf ^ 1, onext); }
       if (!more) break;
       ocur = onext;
       lab_cur = lab_next;
@@ -719,12 +762,13 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     // zero the pad half (channels 12..15) of every plane-1 slot of both buffers once
     for (int i = tid; i < 2 * X_HVP; i += NTHR)
       *reinterpret_cast<u32x2*>(smem + (i / X_HVP) * CF::HALO + X_PLANE + (i % X_HVP) * 16 + 8) = u32x2{0u, 0u};
+    __syncthreads();         // the operand-normalisation table is written
     gload(ocur);
-    sstore(0);
+    sstore(0, ocur);
     __syncthreads();
     if (t + stride < last) { onext = tile_origin(t + stride); gload(onext); }
     compute_tile(F_{}, 0, accA, caddA, ep, accA, caddA);
-    if (t + stride < last) sstore(1);
+    if (t + stride < last) sstore(1, onext);
     __syncthreads();
   } else {
     dma(ocur, 0);
@@ -755,7 +799,7 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     ep_head(odone, ep);
     compute_tile(T_{}, buf, cur, ccur, ep, prv, cprv);
     if constexpr (R12) {
-      if (more) sstore(buf ^ 1);     // halo[buf ^ 1] was last read by the multiplies of the previous tile, behind the last barrier
+      if (more) sstore(buf ^ 1, onext);     // halo[buf ^ 1] was last read by the multiplies of the previous tile, behind the last barrier
       __syncthreads();
     }
   };
@@ -811,6 +855,11 @@ bool conv_halo_x_eligible(const ConvKArgs& a, int dtype, int nclass) {
   if (order < 0) return false;
   if (a.out_f32 && order == 1) return false;        // fp32 output exists for the forward tap order only (the logits)
   return true;                                      // (independent of a.stats: sizing queries run before the partial buffer exists)
+}
+
+// operand normalisation on load: the register-staged (12-wide rows) variant, constants of at most X_NRM_MAXN samples in LDS
+bool conv_halo_x_in_norm_ok(const ConvKArgs& a, int dtype, int nclass) {
+  return conv_halo_x_eligible(a, dtype, nclass) && a.g_ld == 12 && a.Cg == 16 && a.N <= X_NRM_MAXN && a.in_C <= 12;
 }
 
 // InstanceNorm partials exist for the forward tap order with 16-bit output and no addend (what the plans record)
@@ -939,6 +988,7 @@ static void x_fill(const ctseg_conv_desc* d, ConvKArgs& a) {
   a.stats_ld = d->stats_ld; a.stats_tiles = d->stats_tiles; a.stats_tile0 = d->stats_tile0;
   for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
   a.out2 = nullptr; a.out2_col0 = 0; a.o2_ld = 0; a.dtype = d->dtype; a.xcd_order = 0;
+  a.in_mr = d->in_mean_rstd; a.in_alpha = d->in_alpha; a.in_C = d->in_norm_C;
 }
 
 extern "C" int ctseg_conv_logits_ce_slots(const ctseg_conv_desc* d, int32_t C) {

@@ -375,7 +375,11 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
   a.out2 = (char*)d->out2; a.out2_col0 = d->out2_col0; a.o2_ld = d->o2_ld; a.xcd_order = 0;
   a.dtype = d->dtype;
+  a.in_mr = d->in_mean_rstd; a.in_alpha = d->in_alpha; a.in_C = d->in_norm_C;
   const bool halo = conv_halo_eligible(a, d->dtype, d->nclass);
+  if (d->in_mean_rstd != nullptr)
+    CTSEG_REQUIRE(halo && conv_halo_x_in_norm_ok(a, d->dtype, d->nclass) && d->in_alpha != nullptr,
+                  "conv_igemm: in_mean_rstd (normalise the operand on load) is not implemented for this pass (ask ctseg_conv_in_norm_ok)");
   if (halo && d->stats && conv_halo_x_eligible(a, d->dtype, d->nclass))
     CTSEG_REQUIRE(conv_halo_x_stats_ok(a), "conv_igemm: InstanceNorm partials with an addend / fp32 output / input-gradient taps "
                                            "are not implemented on the x-column halo pass");
@@ -422,6 +426,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
 
 static void fill_args(const ctseg_conv_desc* d, ConvKArgs& a) {
   a.out2 = nullptr; a.out2_col0 = 0; a.o2_ld = 0; a.xcd_order = 0; a.dtype = d->dtype;
+  a.in_mr = d->in_mean_rstd; a.in_alpha = d->in_alpha; a.in_C = d->in_norm_C;
   a.w = (const char*)d->w; a.Cn_store = d->Cn_store;
   a.in = (const char*)d->in; a.N = d->N; a.Xi = d->Xi; a.Yi = d->Yi; a.Zi = d->Zi; a.Xr = d->Xr; a.Yr = d->Yr; a.Zr = d->Zr;
   a.Cg = d->Cg; a.Cn = d->Cn; a.g_ld = d->g_ld; a.sin = d->sin; a.sout = d->sout; a.rows = d->Xr * d->Yr * d->Zr;
@@ -445,6 +450,13 @@ extern "C" int ctseg_conv_split_ok(const ctseg_conv_desc* d) {
 
 // 1 when this pass may read / write 12-wide bf16 rows (g_ld, o_ld / Cn_store, add_ld of the descriptor): it is taken by
 // the resident-weight LDS-halo kernel (any of them narrow) or by the stride-2 "up" kernel (narrow output / addend only)
+extern "C" int ctseg_conv_in_norm_ok(const ctseg_conv_desc* d) {
+  if (d == nullptr || !is16(d->dtype) || d->nclass < 1) return 0;
+  ConvKArgs a;
+  fill_args(d, a);
+  return (conv_halo_eligible(a, d->dtype, d->nclass) && conv_halo_x_in_norm_ok(a, d->dtype, d->nclass)) ? 1 : 0;
+}
+
 extern "C" int ctseg_conv_narrow_ok(const ctseg_conv_desc* d) {
   if (d == nullptr || !is16(d->dtype) || d->nclass < 1) return 0;
   ConvKArgs a;

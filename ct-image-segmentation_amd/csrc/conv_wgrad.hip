@@ -388,6 +388,7 @@ int wgrad_stem_slabs(const ctseg_wgrad_desc* d);
 void launch_wgrad_stem(const ctseg_wgrad_desc* d, hipStream_t st);
 bool wgrad_halo_eligible(const ctseg_wgrad_desc* d);
 int wgrad_halo_slabs(const ctseg_wgrad_desc* d);
+bool wgrad_halo_in_norm_ok(const ctseg_wgrad_desc* d);
 void launch_wgrad_halo(const ctseg_wgrad_desc* d, hipStream_t st);
 
 template <typename T, bool SMALLC> static void launch_wgrad(WgradKArgs& a, hipStream_t st) {
@@ -421,6 +422,8 @@ extern "C" int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d) {
   return d->N * d->splits;
 }
 
+extern "C" int ctseg_wgrad_in_norm_ok(const ctseg_wgrad_desc* d) { return (d != nullptr && d->dtype == CTSEG_BF16 && wgrad_halo_in_norm_ok(d)) ? 1 : 0; }
+
 extern "C" int ctseg_wgrad_narrow_ok(const ctseg_wgrad_desc* d) { return (d != nullptr && wgrad_halo_eligible(d)) ? 1 : 0; }
 
 extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
@@ -428,6 +431,9 @@ extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
   CTSEG_REQUIRE(d->dtype == CTSEG_F32 || d->dtype == CTSEG_BF16, "conv_wgrad: bad dtype");
   const int SZ = d->dtype == CTSEG_F32 ? 4 : 2, EPC = 16 / SZ;
   const bool halo = wgrad_halo_eligible(d);     // also moves 12-wide bf16 rows (ctseg_wgrad_narrow_ok)
+  if (d->in_mean_rstd != nullptr)
+    CTSEG_REQUIRE(halo && wgrad_halo_in_norm_ok(d) && d->in_alpha != nullptr,
+                  "conv_wgrad: in_mean_rstd (normalise the operand on load) is not implemented for this pass (ask ctseg_wgrad_in_norm_ok)");
   CTSEG_REQUIRE((d->d_ld % EPC == 0 || halo) && ((uintptr_t)d->dy % 16) == 0, "conv_wgrad: dy must be 16-byte chunked");
   CTSEG_REQUIRE(halo || d->dtype != CTSEG_BF16 || d->g_ld != 12 || d->Cg != 16, "conv_wgrad: 12-wide rows need the LDS-halo kernel");
   const bool smallc = (d->Cg % EPC) != 0 || (d->g_ld % EPC) != 0 || ((uintptr_t)d->in % 16) != 0;

@@ -26,7 +26,13 @@ struct WgradHaloArgs {
   int kpad_w, cn_pad;
   int tiles, txn, tyn, tzn;   // tiles per sample and per axis
   int delta[28];              // halo voxel delta of each tap (in 32-byte rows), entry 27 unused
+  // InstanceNorm + PReLU of the gathered operand on load (ctseg_wgrad_desc::in_mean_rstd): conv_wgrad_head2_kernel only
+  const float* in_mr;
+  const float* in_alpha;
+  int in_C;
 };
+
+constexpr int WH_NRM_MAXN = 16;
 
 constexpr int WH_HV = 600, WH_TV = 256;
 
@@ -410,7 +416,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   constexpr int XN = WH_HV * NPX, DN = WH_TV * NPD, JX = (XN + 511) / 512, JD = (DN + 511) / 512;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   typedef s16x4 __attribute__((address_space(3)))* lds_s16x4;
-  __shared__ __attribute__((aligned(16))) char smem[BUF];
+  __shared__ __attribute__((aligned(16))) char smem[BUF + WH_NRM_MAXN * 128];
+  float* const sPar = reinterpret_cast<float*>(smem + BUF);     // per sample: 4 channel quads x (mean x 4, rstd x 4)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, q4 = lane >> 4;
@@ -461,16 +468,50 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int j = 0; j < JD; ++j)
       rd[j] = (WH_ABL & 4) ? u32x2{(uint32_t)dsf, 0u} : __builtin_amdgcn_raw_buffer_load_b64(dr, (dh[j] & dm) == 0u ? dof[j] : (int)0x80000000, dsf, 0);
   };
-  auto sstore = [&](const u32x2 (&rx)[JX], const u32x2 (&rd)[JD]) {
-    if (WH_ABL & 8) { if (rx[0][0] == 0x12345u && rd[0][0] == 0x54321u) smem[tid] = 1; return; }
+  // operand normalisation on load (the arithmetic of instnorm_prelu_fwd_kernel, rounded to bf16 as that pass rounds): x pieces only;
+  // halo voxels outside the volume and channels >= in_C stay 0.  Piece j holds channel quad (tid + j * 512) % NPX.
+  const bool nrm = P.in_mr != nullptr;
+  const float nrm_al = nrm ? P.in_alpha[0] : 1.f;
+  if (nrm)
+    for (int i = tid; i < P.N * 32; i += 512) {
+      const int n = i >> 5, k = i & 31, c = (k >> 3) * 4 + (k & 3);
+      sPar[i] = c < P.in_C ? P.in_mr[((int64_t)n * P.in_C + c) * 2 + ((k >> 2) & 1)] : 0.f;
+    }
+  auto xmask = [&](int t, int& n) -> uint32_t {
+    n = t / P.tiles;
+    int r = t - n * P.tiles;
+    const int tz = r % P.tzn; r /= P.tzn;
+    const int ty = r % P.tyn, tx = r / P.tyn;
+    const int x0 = tx * 4, y0 = ty * 8, z0 = tz * 8;
+    return ~(range_mask(1 - x0, P.X - x0, 6) | (range_mask(1 - y0, P.Y - y0, 10) << 6) | (range_mask(1 - z0, P.Z - z0, 10) << 16));
+  };
+  auto sstore = [&](int t, const u32x2 (&rx)[JX], const u32x2 (&rd)[JD]) {
+    if (!nrm) {
 #pragma unroll
-    for (int j = 0; j < JX; ++j)
-      if (JX * 512 == XN || tid + j * 512 < XN) *reinterpret_cast<u32x2*>(smem + xl[j]) = rx[j];
+      for (int j = 0; j < JX; ++j)
+        if (JX * 512 == XN || tid + j * 512 < XN) *reinterpret_cast<u32x2*>(smem + xl[j]) = rx[j];
+    } else {
+      int n;
+      const uint32_t xm = xmask(t, n);
+      const float* par = sPar + n * 32;
+#pragma unroll
+      for (int j = 0; j < JX; ++j) {
+        const int part = (tid + j * 512) % NPX;
+        const f32x4 mean = *reinterpret_cast<const f32x4*>(par + part * 8), rstd = *reinterpret_cast<const f32x4*>(par + part * 8 + 4);
+        float v[4] = {h2f<BF16>(rx[j][0] & 0xffffu), h2f<BF16>(rx[j][0] >> 16), h2f<BF16>(rx[j][1] & 0xffffu), h2f<BF16>(rx[j][1] >> 16)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = (v[e] - mean[e]) * rstd[e];
+          v[e] = a > 0.f ? a : nrm_al * a;
+        }
+        const u32x2 w = (xh[j] & xm) == 0u ? u32x2{pack2<BF16>(v[0], v[1]), pack2<BF16>(v[2], v[3])} : u32x2{0u, 0u};
+        if (JX * 512 == XN || tid + j * 512 < XN) *reinterpret_cast<u32x2*>(smem + xl[j]) = w;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < JD; ++j)
       if (JD * 512 == DN || tid + j * 512 < DN) *reinterpret_cast<u32x2*>(smem + dl[j]) = rd[j];
   };
-
   const int kh = wave >> 2, cg = wave & 3;               // k half, combo group
   const int c0 = cg == 0 ? 0 : 2 * cg + 1, nco = cg == 0 ? 3 : 2;      // first (dy,dz) combo of the group, how many
   f32x4 acc[3][3], acc_ps = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -530,16 +571,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // ONE register set of loads in flight per workgroup, FOUR workgroups per CU (128 registers each): the phases of a workgroup
   // (loads -> multiplies -> barrier -> LDS stores -> barrier) do not overlap inside it; they overlap with the other three's.
   u32x2 rxA[JX], rdA[JD];
+  __syncthreads();          // the operand-normalisation table is written
   if (t < tlast) {
     gload(t, rxA, rdA);
-    sstore(rxA, rdA);
+    sstore(t, rxA, rdA);
   }
   __syncthreads();
   for (; t < tlast; t += tstride) {
     if (t + tstride < tlast) gload(t + tstride, rxA, rdA);
     compute();
     __syncthreads();
-    if (t + tstride < tlast) sstore(rxA, rdA);
+    if (t + tstride < tlast) sstore(t + tstride, rxA, rdA);
     __syncthreads();
   }
 
@@ -610,6 +652,8 @@ static bool wgrad_head2(const ctseg_wgrad_desc* d) {
          (d->g_ld == 12 || d->g_ld == 16) && (d->d_ld == 12 || d->d_ld == 16);
 }
 
+bool wgrad_halo_in_norm_ok(const ctseg_wgrad_desc* d) { return wgrad_halo_eligible(d) && wgrad_head2(d) && d->N <= WH_NRM_MAXN && d->in_norm_C <= 12; }
+
 int wgrad_halo_slabs(const ctseg_wgrad_desc* d) { return wgrad_head2(d) ? 2 * wgrad_halo_grid(d) : wgrad_halo_grid(d); }
 
 void launch_wgrad_halo(const ctseg_wgrad_desc* d, hipStream_t st) {
@@ -617,6 +661,7 @@ void launch_wgrad_halo(const ctseg_wgrad_desc* d, hipStream_t st) {
   a.in = (const char*)d->in; a.dy = (const char*)d->dy; a.ws = d->ws;
   a.N = d->N; a.X = d->Xr; a.Y = d->Yr; a.Z = d->Zr; a.Cg = d->Cg; a.g_ld = d->g_ld; a.d_ld = d->d_ld;
   a.kpad_w = d->kpad_w; a.cn_pad = d->cn_pad;
+  a.in_mr = d->in_mean_rstd; a.in_alpha = d->in_alpha; a.in_C = d->in_norm_C;
   a.txn = (d->Xr + 3) / 4; a.tyn = (d->Yr + 7) / 8; a.tzn = (d->Zr + 7) / 8;
   a.tiles = a.txn * a.tyn * a.tzn;
   for (int j = 0; j < 28; ++j) {

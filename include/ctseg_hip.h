@@ -75,6 +75,15 @@ typedef struct ctseg_conv_desc {
    * [skip | sub] gradient of a SkipConnection's torch.cat).  out2 == NULL: feature off. */
   void* out2;
   int32_t out2_col0, o2_ld;
+  /* Optional InstanceNorm + PReLU applied to the GATHERED operand on its way into the pass (where ctseg_conv_in_norm_ok() == 1):
+   * the pass multiplies prelu((in - mean[n][c]) * rstd[n][c]) instead of in, so the normalised activation of the producing layer
+   * (reference: monai Convolution's ADN "NDA" = InstanceNorm3d -> Dropout(0) -> PReLU behind capstone/models/unet.py) is never
+   * written to memory; an identity-residual addend (add == in) is the transformed value as well.
+   * in_mean_rstd: fp32 [N][in_norm_C][2] (mean, 1/sqrt(var + eps)) as ctseg_instnorm_finalize writes it, in_alpha: the PReLU slope
+   * (one value).  NULL: feature off. */
+  const float* in_mean_rstd;
+  const float* in_alpha;
+  int32_t in_norm_C;
 } ctseg_conv_desc;
 
 /* Rows of the row grid / output columns one workgroup tile covers for a pass with Cn columns. */
@@ -91,6 +100,9 @@ int ctseg_conv_split_ok(const ctseg_conv_desc* d);
  * stride-2 transposed "up" pass (output / addend only).  The InstanceNorm, loss and layout entry points take such rows as
  * they are.  The host mirror asks before it lays a tensor out this way and falls back to 16-wide rows otherwise. */
 int ctseg_conv_narrow_ok(const ctseg_conv_desc* d);
+/* 1 if a pass with this geometry can take in_mean_rstd / in_alpha / in_norm_C (pointers are ignored): the x-column LDS-halo pass
+ * over 12-wide 16-bit rows (whose operand is staged through registers), at most 16 samples and 12 normalised channels */
+int ctseg_conv_in_norm_ok(const ctseg_conv_desc* d);
 int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream);
 
 /* Weight gradient: R[tap*Cg+a][b] = sum_rows in[row*sin+d(tap)][a] * dy[row][b]; row K=ntaps*Cg of R is
@@ -108,6 +120,10 @@ typedef struct ctseg_wgrad_desc {
   int32_t taps[CTSEG_MAX_TAPS];
   int32_t splits;        /* row ranges per sample                    */
   int32_t kpad_w, cn_pad; /* slab dims: kpad_w = roundup(ntaps*Cg+1,128), cn_pad = roundup(Cn, tile cols) */
+  /* optional InstanceNorm + PReLU of the gathered operand, as ctseg_conv_desc's (where ctseg_wgrad_in_norm_ok() == 1) */
+  const float* in_mean_rstd;
+  const float* in_alpha;
+  int32_t in_norm_C;
 } ctseg_wgrad_desc;
 
 int ctseg_wgrad_tile_cols(int32_t Cn);
@@ -116,6 +132,8 @@ int ctseg_wgrad_tile_cols(int32_t Cn);
 int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d);
 /* 1 when this weight-gradient pass may read 12-wide bf16 rows (g_ld == 12 with Cg == 16 and / or d_ld == 12): the LDS-halo kernel */
 int ctseg_wgrad_narrow_ok(const ctseg_wgrad_desc* d);
+/* 1 when this weight-gradient pass can normalise its gathered operand on the fly (the 16 -> <= 16 channel LDS-halo kernel) */
+int ctseg_wgrad_in_norm_ok(const ctseg_wgrad_desc* d);
 int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream);
 /* dw[(b*A + a)*T + t] = sum_s ws[s][t*Astride + a][col0 + b]  for a < A, b < nb;
  * db[b] = sum_s ws[s][T*Astride][col0+b] (db may be NULL).  Astride = the pass's (padded) Cg. */
