@@ -354,10 +354,6 @@ class GemmLayer:
         stats = None
         bias_ptr = plan.packer.bias_ptr(self.bias_off)
         pend = getattr(x, "pending_norm", None)
-        if pend is not None and os.environ.get("CTSEG_NORM_ON_LOAD", "1") == "0":
-            x = pend.materialise(x)
-            add = x if add is not None and getattr(add, "pending_norm", None) is pend else add
-            pend = None
         d = self._desc(self.fwd_pack, self.fwd_classes, x, out, rowgrid, sin, sout, self.Cn, self.cg, bias_ptr, add, None, out_f32)
         if pend is not None:
             # the producing layer's InstanceNorm + PReLU is applied to the operand on its way into this pass (the activation is
@@ -442,7 +438,7 @@ class GemmLayer:
         if pend is not None:
             assert not self.transposed
             d.in_mean_rstd, d.in_alpha, d.in_norm_C = pend.mr.data_ptr(), st.p_ptr(pend.alpha), gathered.C
-            if os.environ.get("CTSEG_NORM_ON_LOAD", "1") == "0" or nat.query("ctseg_wgrad_in_norm_ok", d) != 1:
+            if nat.query("ctseg_wgrad_in_norm_ok", d) != 1:
                 gathered = pend.materialise(gathered)
                 d.in_mean_rstd = d.in_alpha = None
                 d.in_norm_C = 0

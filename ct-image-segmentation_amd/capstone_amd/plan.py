@@ -9,6 +9,7 @@ except ``Plan.run``.
 """
 import math
 import os
+import sys
 
 import torch
 import torch.nn as nn
@@ -130,7 +131,12 @@ class _ConvBlock:
         else:   # transposed conv: its bias gradient (sum of dOut over voxels) comes out of the norm's backward pass
             # dOut feeds the generic weight-gradient kernel and the stride-2 input-gradient pass: 16-byte chunked rows
             y = self.na.y
-            dy_wide = new_act(*y.dims, y.C, self.plan.dt, self.plan.device, ld=rup(y.C, nat.epc(self.plan.dt)))
+            # ... except where both consumers take 12-wide rows: the 64 -> <= 12 channel layer of the head (LDS-halo weight gradient
+            # conv_wgrad_up_kernel<12> and the stride-2 halo pass staged in 8-byte pieces), a quarter fewer bytes in three passes
+            gm = self.gemm
+            narrow = (os.environ.get("CTSEG_NARROW_DOUT", "1") != "0" and self.plan.dt == BF16 and gm.transposed and gm.s == 2 and
+                      gm.cin == 64 and self.x.ld == 64 and getattr(gm, "cgd", 0) == 16)
+            dy_wide = new_act(*y.dims, y.C, self.plan.dt, self.plan.device, ld=None if narrow else rup(y.C, nat.epc(self.plan.dt)))
             dy = self.na.emit_bwd(g, dy_out=dy_wide, colsum_out=self.plan.store.g_ptr(bias) if fuse_bias else None)
         self.gemm.emit_wgrad(self.x, dy, bias_done=fuse_bias)
         self.plan.grads_ready(self.params)
@@ -291,7 +297,11 @@ class _Level:
             return self.up0.emit_fwd(self.cat, out=out, out_f32=out_f32)
         # the head (identity-residual unit whose only consumer of the activation is one 3x3x3 conv, its residual and its weight
         # gradient): the transposed conv's InstanceNorm + PReLU is applied by those passes on load, the activation is not written
-        head = self.is_top and self.up1.identity and len(self.up1.units) == 1 and self.up1.nas[0] is None and nat.is16(plan.dt)
+        # MEASURED SLOWER at the reference's shape (round 2, 2 x 512 x 512 x 48 bf16): the apply pass it removes streams at HBM speed
+        # (0.23 ms) while the ~30 VALU operations per staged 8-byte piece cost the fused logits conv + cross-entropy 0.80 -> 1.00 ms
+        # and the logits weight gradient 0.42 -> 0.61 ms (10.49 -> 10.67 ms/step).  Off unless CTSEG_NORM_ON_LOAD=1.
+        head = (os.environ.get("CTSEG_NORM_ON_LOAD", "0") == "1" and self.is_top and self.up1.identity and len(self.up1.units) == 1
+                and self.up1.nas[0] is None and nat.is16(plan.dt))
         a = self.up0.emit_fwd(self.cat, defer_norm=head)
         return self.up1.emit_fwd(a, out=out, out_f32=out_f32)
 
@@ -323,6 +333,29 @@ class _Level:
             plan._defer, plan._stash = plan._stash, None
             plan.flush_deferred()
         return self.down.emit_bwd(gskip, out=out, accumulate=accumulate, need_dx=need_dx)
+
+
+def _make_side_stream(device):
+    """the weight-gradient stream.  CTSEG_SIDE_PRIORITY=low|high: a HIP stream of the least / greatest priority the device offers
+    (hipStreamCreateWithPriority through the runtime library torch already loaded), wrapped for torch; default: a plain stream."""
+    want = os.environ.get("CTSEG_SIDE_PRIORITY", "")
+    if want in ("low", "high"):
+        import ctypes
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+            if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0:
+                h = ctypes.c_void_p()
+                prio = least.value if want == "low" else greatest.value
+                with torch.cuda.device(device):
+                    rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(prio))   # 1 = hipStreamNonBlocking
+                if rc == 0 and h.value:
+                    if os.environ.get("CTSEG_SIDE_PRIORITY_VERBOSE"):
+                        print(f"side stream priority {prio} (range {least.value}..{greatest.value})", file=sys.stderr)
+                    return torch.cuda.ExternalStream(h.value, device=device)
+        except OSError:
+            pass
+    return torch.cuda.Stream(device=device)
 
 
 class Plan:
@@ -474,7 +507,7 @@ class Plan:
 
     def _side_setup(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = _make_side_stream(self.device)
             self._side_edges = [i for i in range(len(self.bwd) + 1)
                                 if i == 0 or i == len(self.bwd) or
                                 (self.bwd[i][0] in self.SIDE_OPS) != (self.bwd[i - 1][0] in self.SIDE_OPS)]

@@ -16,6 +16,7 @@
 // odd) 16-byte slots, and the XOR puts the other b-row (hb differs by 2) on the opposite parity: every ds_read_b128 phase
 // hits 16 distinct slots for every tap.
 #include "conv_common.h"
+#include <type_traits>
 
 namespace ctseg {
 
@@ -42,11 +43,15 @@ struct DownGeom {
   int tbn, tcn, tiles;
 };
 
-template <typename H, int VB, bool STATS>     // H = 16-bit storage kind (BF16 / F16)
+// R12: the gathered rows are 12 elements wide (24 bytes: the <= 12-channel gradient of the head's transposed conv): staged in
+// 8-byte pieces (3 per voxel) into the same two-plane image; the upper half of every plane-1 slot is zeroed once.
+template <typename H, int VB, bool STATS, bool R12 = false>     // H = 16-bit storage kind (BF16 / F16)
 __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs P, const DownGeom G, int total_tiles) {
+  static_assert(!R12 || VB == 32, "12-wide rows: 16 gathered channels");
   using CF = DownCfg<VB>;
   constexpr int TA = CF::TA, HA = CF::HA, NPL = CF::NPL, PLANE = CF::PLANE, CG = CF::CG, RG = CF::G;
-  constexpr int FV = HA * 17 * 17, NCH = FV * NPL, J = (NCH + DH_NTHR - 1) / DH_NTHR;
+  constexpr int FV = HA * 17 * 17, NCH = FV * (R12 ? 3 : NPL), J = (NCH + DH_NTHR - 1) / DH_NTHR;
+  using RH = std::conditional_t<R12, u32x2, u32x4>;
   constexpr int NU = (27 * CG + 31) / 32;                 // 32-wide k-steps that carry real taps
   constexpr int NKS = (NU + 1) / 2;                       // 128-byte K stages to stream
   constexpr int NRS = (NKS + RG - 1) / RG;                // ring stages per tile
@@ -79,15 +84,23 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
   }
 
   // ---- halo staging slots -----------------------------------------------------------------------------------------------
-  int g_byte[J], g_fabc[J], g_lds[J];
+  int g_byte[J], g_fabc[R12 ? 1 : J], g_lds[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const int idx = tid + j * DH_NTHR;
-    const int pl = (idx >> 3) % NPL, fv = (idx / (8 * NPL)) * 8 + (idx & 7);
+    // 16-byte chunks: 8 consecutive threads take 8 consecutive voxels of one plane; 8-byte pieces (R12): voxel-major, 3 per voxel
+    const int pl = R12 ? idx % 3 : (idx >> 3) % NPL, fv = R12 ? idx / 3 : (idx / (8 * NPL)) * 8 + (idx & 7);
     const int fa = fv / (17 * 17), rem = fv - fa * (17 * 17), fb = rem / 17, fc = rem - fb * 17;
-    g_byte[j] = ((fa * G.ia + fb * G.ib + fc * G.ic) * P.g_ld + pl * 8) * 2;
-    g_fabc[j] = (fv < FV) ? (fa | (fb << 8) | (fc << 16)) : 0x7f7f7f;
-    g_lds[j] = pl * PLANE + ((fa * DH_HB + fb) * DH_HC + (fc ^ ((fb >> 1) & 1))) * 16;
+    const int slot16 = ((fa * DH_HB + fb) * DH_HC + (fc ^ ((fb >> 1) & 1))) * 16;
+    if constexpr (R12) {
+      // byte offset from the halo origin (sign bit: no such piece); LDS offset (a multiple of 8) | "first halo plane along a / b / c"
+      g_byte[j] = fv < FV ? (fa * G.ia + fb * G.ib + fc * G.ic) * P.g_ld * 2 + pl * 8 : (int)0x80000000;
+      g_lds[j] = ((pl == 2 ? PLANE : 0) + slot16 + (pl == 1 ? 8 : 0)) | (fa == 0 ? 1 : 0) | (fb == 0 ? 2 : 0) | (fc == 0 ? 4 : 0);
+    } else {
+      g_byte[j] = ((fa * G.ia + fb * G.ib + fc * G.ic) * P.g_ld + pl * 8) * 2;
+      g_fabc[j] = (fv < FV) ? (fa | (fb << 8) | (fc << 16)) : 0x7f7f7f;
+      g_lds[j] = pl * PLANE + slot16;
+    }
   }
   auto tile_origin = [&](int t, int& n, int& a0, int& b0, int& c0) {
     n = t / G.tiles;
@@ -97,25 +110,42 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
     a0 = ta * TA; b0 = tb * 8; c0 = tc * 8;
   };
   const int64_t in_sample = (int64_t)P.Xi * P.Yi * P.Zi, out_sample = (int64_t)P.Xo * P.Yo * P.Zo;
-  u32x4 rh[J];
+  RH rh[J];
+  if constexpr (R12) {
+    for (int i = tid; i < CF::HV; i += DH_NTHR) *reinterpret_cast<u32x2*>(sH + PLANE + i * 16 + 8) = u32x2{0u, 0u};
+  }
   auto gload = [&](int t) {
     int n, a0, b0, c0;
     tile_origin(t, n, a0, b0, c0);
-    const int ai0 = 2 * a0 - 1, bi0 = 2 * b0 - 1, ci0 = 2 * c0 - 1;       // input coordinate of halo (0,0,0)
-    const char* base = P.in + (n * in_sample + (int64_t)ai0 * G.ia + (int64_t)bi0 * G.ib + (int64_t)ci0 * G.ic) * P.g_ld * 2;
+    if constexpr (R12) {
+      // the input is exactly twice the row grid (host-checked): only the -1 taps of the first tile along an axis leave the volume;
+      // what a partial tile reads past the grid feeds rows that are not stored (finite, or zero past the end of the sample)
+      const int bias = (G.ia + G.ib + G.ic) * P.g_ld * 2, sb = (int)(in_sample * P.g_ld * 2);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.in) + (int64_t)n * sb - bias, 0, sb + bias, 0x00020000);
+      const int soff = (2 * a0 * G.ia + 2 * b0 * G.ib + 2 * c0 * G.ic) * P.g_ld * 2;
+      const int m = (a0 == 0 ? 1 : 0) | (b0 == 0 ? 2 : 0) | (c0 == 0 ? 4 : 0);
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int ai = ai0 + (g_fabc[j] & 0xff), bi = bi0 + ((g_fabc[j] >> 8) & 0xff), ci = ci0 + (g_fabc[j] >> 16);
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if ((unsigned)ai < (unsigned)G.xa && (unsigned)bi < (unsigned)G.xb && (unsigned)ci < (unsigned)G.xc)
-        v = *reinterpret_cast<const u32x4*>(base + g_byte[j]);
-      rh[j] = v;
+      for (int j = 0; j < J; ++j)
+        rh[j] = __builtin_amdgcn_raw_buffer_load_b64(rs, ((g_lds[j] & m) == 0 && g_byte[j] >= 0) ? g_byte[j] : (int)0x80000000, soff, 0);
+    } else {
+      const int ai0 = 2 * a0 - 1, bi0 = 2 * b0 - 1, ci0 = 2 * c0 - 1;       // input coordinate of halo (0,0,0)
+      const char* base = P.in + (n * in_sample + (int64_t)ai0 * G.ia + (int64_t)bi0 * G.ib + (int64_t)ci0 * G.ic) * P.g_ld * 2;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int ai = ai0 + (g_fabc[j] & 0xff), bi = bi0 + ((g_fabc[j] >> 8) & 0xff), ci = ci0 + (g_fabc[j] >> 16);
+        RH v = {};
+        if ((unsigned)ai < (unsigned)G.xa && (unsigned)bi < (unsigned)G.xb && (unsigned)ci < (unsigned)G.xc)
+          v = *reinterpret_cast<const RH*>(base + g_byte[j]);
+        rh[j] = v;
+      }
     }
   };
   auto sstore = [&]() {
 #pragma unroll
-    for (int j = 0; j < J; ++j)
-      if ((g_fabc[j] & 0xff) != 0x7f) *reinterpret_cast<u32x4*>(sH + g_lds[j]) = rh[j];
+    for (int j = 0; j < J; ++j) {
+      if constexpr (R12) { if (g_byte[j] >= 0) *reinterpret_cast<RH*>(sH + (g_lds[j] & ~7)) = rh[j]; }
+      else { if ((g_fabc[j] & 0xff) != 0x7f) *reinterpret_cast<RH*>(sH + g_lds[j]) = rh[j]; }
+    }
   };
 
   // ---- weight stream ---------------------------------------------------------------------------------------------------
@@ -335,7 +365,8 @@ bool conv_down_halo_eligible(const ConvKArgs& a, int dtype, int nclass) {
   // 32 gathered channels -> 128 columns was measured SLOWER than the generic kernel (128-row tiles do not amortise the 221 KB
   // weight stream): only the 16-channel case runs here
   if (vb != 32 || a.Cn < 48 || (a.Cn_store % 4) != 0) return false;
-  if ((a.g_ld % 8) != 0 || ((uintptr_t)a.in % 16) != 0 || ((uintptr_t)a.w % 16) != 0) return false;
+  if (((a.g_ld % 8) != 0 && a.g_ld != 12) || ((uintptr_t)a.in % 16) != 0 || ((uintptr_t)a.w % 16) != 0) return false;   // 12: 8-byte pieces
+  if (a.g_ld == 12 && (a.Xi != 2 * a.Xr || a.Yi != 2 * a.Yr || a.Zi != 2 * a.Zr)) return false;        // (only the -1 taps leave the volume)
   if (a.Xo != a.Xr || a.Yo != a.Yr || a.Zo != a.Zr) return false;
   if (2 * a.Xr - 1 > a.Xi + 1 || 2 * a.Yr - 1 > a.Yi + 1 || 2 * a.Zr - 1 > a.Zi + 1) return false;   // rows whose centre lies outside
   if ((int64_t)a.Xi * a.Yi * a.Zi * a.g_ld * 2 >= (1ll << 31)) return false;
@@ -369,13 +400,16 @@ void launch_conv_down_halo(ConvKArgs& a, hipStream_t st) {
   const int total = g.tiles * a.N;
   const dim3 grid((unsigned)down_grid(a, g), (unsigned)((a.Cn + DH_CN - 1) / DH_CN)), blk(DH_NTHR);
   const bool stats = a.stats != nullptr;
+#define CTSEG_DH_GO(H, ST, R) hipLaunchKernelGGL((conv_down_halo_kernel<H, 32, ST, R>), grid, blk, 0, st, a, g, total)
+  const bool r12 = a.g_ld == 12;
   if (a.dtype == CTSEG_F16) {
-    if (stats) hipLaunchKernelGGL((conv_down_halo_kernel<F16, 32, true>), grid, blk, 0, st, a, g, total);
-    else hipLaunchKernelGGL((conv_down_halo_kernel<F16, 32, false>), grid, blk, 0, st, a, g, total);
+    if (stats) { if (r12) CTSEG_DH_GO(F16, true, true); else CTSEG_DH_GO(F16, true, false); }
+    else { if (r12) CTSEG_DH_GO(F16, false, true); else CTSEG_DH_GO(F16, false, false); }
   } else {
-    if (stats) hipLaunchKernelGGL((conv_down_halo_kernel<BF16, 32, true>), grid, blk, 0, st, a, g, total);
-    else hipLaunchKernelGGL((conv_down_halo_kernel<BF16, 32, false>), grid, blk, 0, st, a, g, total);
+    if (stats) { if (r12) CTSEG_DH_GO(BF16, true, true); else CTSEG_DH_GO(BF16, true, false); }
+    else { if (r12) CTSEG_DH_GO(BF16, false, true); else CTSEG_DH_GO(BF16, false, false); }
   }
+#undef CTSEG_DH_GO
 }
 
 }  // namespace ctseg

@@ -406,7 +406,8 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
                   "conv_igemm: stats partial layout (need stats_ld >= roundup(Cn, tile cols))");
   }
   if (n_out || n_in || n_add)
-    CTSEG_REQUIRE(halo || (up && !n_in), "conv_igemm: 12-wide bf16 rows are moved by the LDS-halo passes only (ask ctseg_conv_narrow_ok)");
+    CTSEG_REQUIRE(halo || (up && !n_in) || (down && !n_out && !n_add),
+                  "conv_igemm: 12-wide bf16 rows are moved by the LDS-halo passes only (ask ctseg_conv_narrow_ok)");
   if (d->out2 != nullptr)
     CTSEG_REQUIRE((stem || down) && d->add == nullptr && d->out2_col0 > 0 && d->out2_col0 % 4 == 0 && d->out2_col0 < d->Cn_store &&
                       d->o2_ld >= d->Cn_store - d->out2_col0 && d->o2_ld % 4 == 0 && ((uintptr_t)d->out2 % 16) == 0,
@@ -448,8 +449,6 @@ extern "C" int ctseg_conv_split_ok(const ctseg_conv_desc* d) {
   return conv_down_halo_eligible(a, d->dtype, d->nclass) ? 1 : 0;
 }
 
-// 1 when this pass may read / write 12-wide bf16 rows (g_ld, o_ld / Cn_store, add_ld of the descriptor): it is taken by
-// the resident-weight LDS-halo kernel (any of them narrow) or by the stride-2 "up" kernel (narrow output / addend only)
 extern "C" int ctseg_conv_in_norm_ok(const ctseg_conv_desc* d) {
   if (d == nullptr || !is16(d->dtype) || d->nclass < 1) return 0;
   ConvKArgs a;
@@ -457,13 +456,20 @@ extern "C" int ctseg_conv_in_norm_ok(const ctseg_conv_desc* d) {
   return (conv_halo_eligible(a, d->dtype, d->nclass) && conv_halo_x_in_norm_ok(a, d->dtype, d->nclass)) ? 1 : 0;
 }
 
+// 1 when this pass may read / write 12-wide bf16 rows (g_ld, o_ld / Cn_store, add_ld of the descriptor): it is taken by
+// the resident-weight LDS-halo kernel (any of them narrow), by the stride-2 "up" kernel (narrow output / addend only) or by the
+// stride-2 "down" halo kernel (narrow gathered operand only)
 extern "C" int ctseg_conv_narrow_ok(const ctseg_conv_desc* d) {
   if (d == nullptr || !is16(d->dtype) || d->nclass < 1) return 0;
   ConvKArgs a;
   fill_args(d, a);
   a.out_f32 = d->out_f32; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo; a.add = (const char*)d->add; a.o_ld = d->o_ld;
   if (conv_halo_eligible(a, d->dtype, d->nclass)) return 1;
-  if (d->g_ld % 8 != 0) return 0;
+  if (d->g_ld % 8 != 0) {
+    const bool wide_out = d->out_f32 || (d->o_ld % 8 == 0 && d->Cn_store % 8 == 0), wide_add = d->add == nullptr || d->add_f32 || d->add_ld % 8 == 0;
+    return (d->g_ld == 12 && wide_out && wide_add && !conv_up_eligible(a, d->dtype, d->nclass) && !conv_stem_eligible(a, d->dtype, d->nclass) &&
+            !conv_halo_sw_eligible(a, d->dtype, d->nclass) && conv_down_halo_eligible(a, d->dtype, d->nclass)) ? 1 : 0;
+  }
   return conv_up_eligible(a, d->dtype, d->nclass) ? 1 : 0;
 }
 

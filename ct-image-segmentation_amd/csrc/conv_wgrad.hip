@@ -424,7 +424,11 @@ extern "C" int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d) {
 
 extern "C" int ctseg_wgrad_in_norm_ok(const ctseg_wgrad_desc* d) { return (d != nullptr && d->dtype == CTSEG_BF16 && wgrad_halo_in_norm_ok(d)) ? 1 : 0; }
 
-extern "C" int ctseg_wgrad_narrow_ok(const ctseg_wgrad_desc* d) { return (d != nullptr && wgrad_halo_eligible(d)) ? 1 : 0; }
+extern "C" int ctseg_wgrad_narrow_ok(const ctseg_wgrad_desc* d) {
+  if (d == nullptr) return 0;
+  if (wgrad_halo_eligible(d)) return 1;
+  return (d->d_ld != 12 && wgrad_up_eligible(d)) ? 1 : 0;      // the stride-2 transposed-conv kernel takes a 12-wide gathered operand
+}
 
 extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
   CTSEG_REQUIRE(d != nullptr && d->in && d->dy && d->ws, "conv_wgrad: null pointer");
@@ -435,7 +439,8 @@ extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
     CTSEG_REQUIRE(halo && wgrad_halo_in_norm_ok(d) && d->in_alpha != nullptr,
                   "conv_wgrad: in_mean_rstd (normalise the operand on load) is not implemented for this pass (ask ctseg_wgrad_in_norm_ok)");
   CTSEG_REQUIRE((d->d_ld % EPC == 0 || halo) && ((uintptr_t)d->dy % 16) == 0, "conv_wgrad: dy must be 16-byte chunked");
-  CTSEG_REQUIRE(halo || d->dtype != CTSEG_BF16 || d->g_ld != 12 || d->Cg != 16, "conv_wgrad: 12-wide rows need the LDS-halo kernel");
+  CTSEG_REQUIRE(halo || wgrad_up_eligible(d) || d->dtype != CTSEG_BF16 || d->g_ld != 12 || d->Cg != 16,
+                "conv_wgrad: 12-wide rows need an LDS-halo kernel");
   const bool smallc = (d->Cg % EPC) != 0 || (d->g_ld % EPC) != 0 || ((uintptr_t)d->in % 16) != 0;
   CTSEG_REQUIRE(d->ntaps >= 1 && d->ntaps <= CTSEG_MAX_TAPS && d->splits >= 1, "conv_wgrad: ntaps/splits");
   const int bnw = ctseg_wgrad_tile_cols(d->Cn);

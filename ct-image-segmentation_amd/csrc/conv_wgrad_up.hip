@@ -50,15 +50,22 @@ struct WgradUpArgs {
 
 constexpr int WU_TX = 4, WU_TY = 4, WU_TZ = 8;                       // coarse tile
 constexpr int WU_HX = 2 * WU_TX + 1, WU_HY = 2 * WU_TY + 1, WU_HZ = 2 * WU_TZ + 1;   // 9 x 9 x 17 fine halo
-constexpr int WU_FPIECES = WU_HX * WU_HY * WU_HZ * 2;                // 16-byte pieces of the fine halo (2754)
+constexpr int WU_FPIECES = WU_HX * WU_HY * WU_HZ * 2;                // half-row pieces of the fine halo (2754): 16 or 12 bytes each
 constexpr int WU_FINSTR = (WU_FPIECES + 63) / 64;                    // 44 DMA instructions
-constexpr int WU_FBYTES = WU_FINSTR * 1024;
+constexpr int WU_FBYTES = WU_FINSTR * 1024;                          // (16-wide rows; 12-wide rows use 44 x 768 of it)
 constexpr int WU_CINSTR = 16;                                        // 4 channel blocks x 4 coarse planes, 32 voxels x 32 B each
 constexpr int WU_CBYTES = WU_CINSTR * 1024;
 constexpr int WU_FJ = WU_FINSTR / 4, WU_CJ = WU_CINSTR / 4;          // per wave
 static_assert(WU_FINSTR % 4 == 0, "every wave issues the same number of DMA instructions");
 
+// GW = elements of a fine row in memory: 16, or 12 (24-byte rows of the <= 12-channel gradient).  A 12-byte LDS-DMA piece lands
+// in a 16-byte LDS slot like a 16-byte one (lane l writes bytes [16 l, 16 l + 12): measured, tools/probe_lds_dma12.hip), so the LDS
+// image keeps its 32-byte voxel slots with channels 0-5 | 4 bytes never written | channels 6-11 | 4 bytes never written: the
+// transposed reads are unchanged and operand row a' of the MFMA holds channel a' (a' < 6) or a' - 2 (8 <= a' < 14); rows 6, 7, 14,
+// 15 multiply the zeroed gaps and are not written to the slab.
+template <int GW>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_up_kernel(const WgradUpArgs P, int total_tiles) {
+  constexpr int FS = 32, PB = GW == 16 ? 16 : 12, GB = GW * 2;     // LDS voxel slot, bytes per DMA piece, bytes of a row in memory
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   typedef s16x4 __attribute__((address_space(3)))* lds_s16x4;
   __shared__ __attribute__((aligned(16))) char smem[WU_FBYTES + WU_CBYTES];
@@ -78,14 +85,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_up_kernel(const WgradUpArgs
     const int idx = (wave + 4 * j) * 64 + lane, s = idx >> 1, half = idx & 1;
     const int hx = s / (WU_HY * WU_HZ), rem = s - hx * (WU_HY * WU_HZ), hy = rem / WU_HZ, e = rem - hy * WU_HZ;
     const int hz = e < 9 ? 2 * e : 2 * (e - 9) + 1;
-    const int off = ((hx * Yf + hy) * Zf + hz) * 32 + half * 16;
-    fpk[j] = idx < WU_FPIECES ? (off | (hx == 0 ? 1 : 0) | (hy == 0 ? 2 : 0) | (hz == 0 ? 4 : 0)) : 8;
+    const int off = ((hx * Yf + hy) * Zf + hz) * GB + half * PB;
+    fpk[j] = idx < WU_FPIECES ? (off * 4 + ((hx == 0 ? 1 : 0) | (hy == 0 ? 2 : 0) | (hz == 0 ? 4 : 0))) : 8;      // (12-byte offsets have no free low bits)
   }
   // coarse pieces: instruction i = (channel block nb = i >> 2, plane p = i & 3); lane -> (voxel (ly_c, lz_c), 16-byte half)
   const int cly = lane >> 4, clz = (lane >> 1) & 7;
   const int coff = (cly * P.Z + clz) * 128 + (lane & 1) * 16;
   const uint32_t chot = (1u << cly) | (1u << (4 + clz));
-  const int fbias = (Yf * Zf + Zf + 1) * 32;
+  const int fbias = (Yf * Zf + Zf + 1) * GB;
 
   auto range_mask = [](int hi, int nbits) -> uint32_t {     // bits 0..hi (clamped)
     hi = hi > nbits - 1 ? nbits - 1 : hi;
@@ -99,11 +106,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_up_kernel(const WgradUpArgs
     const int x0 = tx * WU_TX, y0 = ty * WU_TY, z0 = tz * WU_TZ;
     const int fm = (x0 == 0 ? 1 : 0) | (y0 == 0 ? 2 : 0) | (z0 == 0 ? 4 : 0) | 8;
     const wu_i32x4 fr = wu_make_rsrc(P.fine + (int64_t)n * P.fine_sample_bytes - fbias, (uint32_t)(P.fine_sample_bytes + fbias));
-    const int fso = ((2 * x0 * Yf + 2 * y0) * Zf + 2 * z0) * 32;
+    const int fso = ((2 * x0 * Yf + 2 * y0) * Zf + 2 * z0) * GB;
 #pragma unroll
     for (int j = 0; j < WU_FJ; ++j) {
-      const int vo = (fpk[j] & fm) == 0 ? (fpk[j] & ~15) : (int)0x80000000;
-      wu_buffer_load_lds(fr, (wu_lds_ptr)(smem + (wave + 4 * j) * 1024), 16, vo, fso, 0, 0);
+      const int vo = (fpk[j] & fm) == 0 ? (int)((unsigned)fpk[j] >> 4 << 2) : (int)0x80000000;
+      wu_buffer_load_lds(fr, (wu_lds_ptr)(smem + (wave + 4 * j) * 1024), PB, vo, fso, 0, 0);
     }
     const wu_i32x4 cr = wu_make_rsrc(P.coarse + (int64_t)n * P.coarse_sample_bytes, (uint32_t)P.coarse_sample_bytes);
     const uint32_t cnot = ~(range_mask(P.Y - y0 - 1, 4) | (range_mask(P.Z - z0 - 1, 8) << 4));
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_up_kernel(const WgradUpArgs
     const short o = (r16 == 0) ? (short)0x3f80 : (short)0;
     ones = s16x8{o, o, o, o, o, o, o, o};
   }
-  const char* abase = smem + ((2 * ly) * WU_HZ + lz) * 32 + tp * 8;                      // fine halo (plane 0, row 2 ly, entry lz)
+  const char* abase = smem + ((2 * ly) * WU_HZ + lz) * FS + tp * 8;                      // fine halo (plane 0, row 2 ly, entry lz)
   const char* bbase = smem + WU_FBYTES + (2 * nh) * 4096 + (ly * 8 + lz) * 32 + tp * 8;   // coarse block 2 nh, plane 0
   auto compute = [&]() {
     bf16x8 bf[4][2];
@@ -149,10 +156,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_up_kernel(const WgradUpArgs
       if (ci < nco) {                                  // wave-uniform
         const int c = c0 + ci, ty = c / 3, tz = c - 3 * ty;
         const int ez = tz == 0 ? 0 : (tz == 1 ? 9 : 1);                                   // even[lz], odd[lz], even[lz + 1]
-        const char* ab = abase + (ty * WU_HZ + ez) * 32;
+        const char* ab = abase + (ty * WU_HZ + ez) * FS;
 #pragma unroll
         for (int f = 0; f < WU_HX; ++f) {
-          const bf16x8 af = tr_frag(ab + f * (WU_HY * WU_HZ * 32), 4 * WU_HZ * 32);       // second half: coarse y + 2 = fine row + 4
+          const bf16x8 af = tr_frag(ab + f * (WU_HY * WU_HZ * FS), 4 * WU_HZ * FS);       // second half: coarse y + 2 = fine row + 4
 #pragma unroll
           for (int tx = 0; tx < 3; ++tx) {
             if ((f - tx) % 2 != 0 || f - tx < 0 || f - tx > 6) continue;                  // fine plane f = 2 p + tx
@@ -178,6 +185,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_up_kernel(const WgradUpArgs
     tstride = gridDim.x >> 3;
     tlast = (xcd + 1) * chunk < total_tiles ? (xcd + 1) * chunk : total_tiles;
   }
+  if constexpr (GW == 12) {       // the 4-byte gaps behind every 12-byte piece are never written again
+    for (int i = tid; i < WU_FBYTES / 16; i += 256) *reinterpret_cast<uint32_t*>(smem + i * 16 + 12) = 0u;
+    __syncthreads();
+  }
   if (t < tlast) dma(t);
   for (; t < tlast; t += tstride) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -197,7 +208,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_up_kernel(const WgradUpArgs
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) slab[(int64_t)(tap * 16 + 4 * q4 + e) * P.cn_pad + (2 * nh + nb) * 16 + r16] = acc[ci][tx][nb][e];
+        for (int e = 0; e < 4; ++e) {
+          const int ar = 4 * q4 + e;                                         // operand row -> gathered channel
+          const int ch = GW == 16 ? ar : ((ar & 7) < 6 ? ar - (ar >> 3) * 2 : -1);
+          if (ch >= 0) slab[(int64_t)(tap * 16 + ch) * P.cn_pad + (2 * nh + nb) * 16 + r16] = acc[ci][tx][nb][e];
+        }
     }
   }
   if (grp == 1) {
@@ -211,12 +226,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_up_kernel(const WgradUpArgs
 
 bool wgrad_up_eligible(const ctseg_wgrad_desc* d) {
   if (getenv("CTSEG_NO_WGRAD_UP") != nullptr) return false;
-  if (d->dtype != CTSEG_BF16 || d->sin != 2 || d->ntaps != 27 || d->Cg != 16 || d->g_ld != 16 || d->Cn != 64 || d->d_ld != 64) return false;
+  if (d->dtype != CTSEG_BF16 || d->sin != 2 || d->ntaps != 27 || d->Cg != 16 || (d->g_ld != 16 && d->g_ld != 12) || d->Cn != 64 || d->d_ld != 64) return false;
   if (d->Xi != 2 * d->Xr || d->Yi != 2 * d->Yr || d->Zi != 2 * d->Zr) return false;
   if (d->kpad_w < 27 * 16 || d->cn_pad < 64) return false;
-  if (d->in != nullptr && ((uintptr_t)d->in % 16) != 0) return false;
+  if (d->in != nullptr && ((uintptr_t)d->in % 16) != 0) return false;       // (12-wide rows: 4-byte aligned pieces)
   if (d->dy != nullptr && ((uintptr_t)d->dy % 16) != 0) return false;
-  const int64_t fb = (int64_t)d->Xi * d->Yi * d->Zi * 32 + ((int64_t)d->Yi * d->Zi + d->Zi + 1) * 32, cb = (int64_t)d->Xr * d->Yr * d->Zr * 128;
+  const int64_t fb = ((int64_t)d->Xi * d->Yi * d->Zi + (int64_t)d->Yi * d->Zi + d->Zi + 1) * d->g_ld * 2, cb = (int64_t)d->Xr * d->Yr * d->Zr * 128;
+  if (fb >= (1ll << 29)) return false;      // piece offsets are kept shifted left by 2 beside their flags
   if (fb >= (1ll << 31) || cb >= (1ll << 31)) return false;
   for (int j = 0; j < 27; ++j) {       // taps are indexed tx * 9 + ty * 3 + tz
     const int tp = d->taps[j];
@@ -243,9 +259,10 @@ void launch_wgrad_up(const ctseg_wgrad_desc* d, hipStream_t st) {
   a.kpad_w = d->kpad_w; a.cn_pad = d->cn_pad;
   a.tyn = (d->Yr + WU_TY - 1) / WU_TY; a.tzn = (d->Zr + WU_TZ - 1) / WU_TZ;
   a.tiles = ((d->Xr + WU_TX - 1) / WU_TX) * a.tyn * a.tzn;
-  a.fine_sample_bytes = (int)((int64_t)d->Xi * d->Yi * d->Zi * 32);
+  a.fine_sample_bytes = (int)((int64_t)d->Xi * d->Yi * d->Zi * d->g_ld * 2);
   a.coarse_sample_bytes = (int)((int64_t)d->Xr * d->Yr * d->Zr * 128);
-  hipLaunchKernelGGL(conv_wgrad_up_kernel, dim3(wgrad_up_grid(d)), dim3(256), 0, st, a, a.tiles * d->N);
+  if (d->g_ld == 12) hipLaunchKernelGGL(conv_wgrad_up_kernel<12>, dim3(wgrad_up_grid(d)), dim3(256), 0, st, a, a.tiles * d->N);
+  else hipLaunchKernelGGL(conv_wgrad_up_kernel<16>, dim3(wgrad_up_grid(d)), dim3(256), 0, st, a, a.tiles * d->N);
 }
 
 }  // namespace ctseg

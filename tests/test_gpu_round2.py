@@ -588,3 +588,39 @@ def test_head_norm_on_load_fp16_inference(monkeypatch):
         with torch.no_grad():
             outs.append(m(x).float().clone())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("cout,shape", [(10, (2, 10, 16, 16)), (12, (1, 13, 13, 17)), (10, (1, 16, 16, 16))])
+def test_head_transposed_conv_backward_reads_12_wide_gradient_rows(cout, shape):
+    """dOut of the head's ConvTranspose3d(64 -> <= 12) laid out 12 elements wide (24-byte rows): its weight gradient
+    (conv_wgrad_up_kernel<12>: 12-byte LDS-DMA pieces) and its input gradient (the stride-2 halo pass staged in 8-byte pieces)
+    give the BITS of the 16-wide layout, and agree with torch on the CPU.  Ragged tiles, several samples."""
+    from capstone_amd import _native as nat
+    from capstone_amd.engine import GemmLayer
+    from helpers import MiniPlan, to_cl, from_cl, rel_err
+    torch.manual_seed(cout + shape[2])
+    mod = torch.nn.ConvTranspose3d(64, cout, 3, 2, 1, output_padding=1)
+    x = torch.randn(shape[0], 64, *shape[1:])
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    ref_gx, ref_gw = xr.grad.clone(), mod.weight.grad.detach().clone()      # (the plans below re-home the parameters and their .grad)
+    res = {}
+    for ld in (16, 12):
+        plan = MiniPlan([mod.weight, mod.bias], DEV, nat.BF16, 3)
+        layer = GemmLayer(plan, "t", True, 3, 2, 64, [(mod.weight, mod.bias, cout)], 64)
+        plan.packer.finalize()
+        xa = to_cl(x, nat.BF16, DEV)
+        layer.emit_fwd(xa)
+        plan.run()
+        ga = to_cl(gy, nat.BF16, DEV, ld=ld)
+        gxa = layer.emit_dgrad(ga)
+        plan.run()
+        layer.emit_wgrad(xa, ga, bias_done=True)      # (the plan takes the bias gradient from the norm-backward pass)
+        plan.run()
+        torch.cuda.synchronize()
+        res[ld] = (from_cl(gxa).clone(), plan.store.grad_view(mod.weight).cpu().clone())
+    assert rel_err(res[12][0], ref_gx) < 2.5e-2 and rel_err(res[12][1], ref_gw) < 2.5e-2
+    assert torch.equal(res[12][0], res[16][0]), "input gradient"
+    assert torch.equal(res[12][1], res[16][1]), "weight gradient"
