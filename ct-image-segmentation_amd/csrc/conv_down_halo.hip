@@ -129,14 +129,15 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
         rh[j] = __builtin_amdgcn_raw_buffer_load_b64(rs, ((g_lds[j] & m) == 0 && g_byte[j] >= 0) ? g_byte[j] : (int)0x80000000, soff, 0);
     } else {
       const int ai0 = 2 * a0 - 1, bi0 = 2 * b0 - 1, ci0 = 2 * c0 - 1;       // input coordinate of halo (0,0,0)
-      const char* base = P.in + (n * in_sample + (int64_t)ai0 * G.ia + (int64_t)bi0 * G.ib + (int64_t)ci0 * G.ic) * P.g_ld * 2;
+      // branch-free (plain loads under `if (inside)` were waited for one by one): out-of-volume voxels get an out-of-range offset
+      const int bias = (G.ia + G.ib + G.ic) * P.g_ld * 2, sb = (int)(in_sample * P.g_ld * 2);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.in) + (int64_t)n * sb - bias, 0, sb + bias, 0x00020000);
+      const int soff = (2 * a0 * G.ia + 2 * b0 * G.ib + 2 * c0 * G.ic) * P.g_ld * 2;
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int ai = ai0 + (g_fabc[j] & 0xff), bi = bi0 + ((g_fabc[j] >> 8) & 0xff), ci = ci0 + (g_fabc[j] >> 16);
-        RH v = {};
-        if ((unsigned)ai < (unsigned)G.xa && (unsigned)bi < (unsigned)G.xb && (unsigned)ci < (unsigned)G.xc)
-          v = *reinterpret_cast<const RH*>(base + g_byte[j]);
-        rh[j] = v;
+        const bool inside = (unsigned)ai < (unsigned)G.xa && (unsigned)bi < (unsigned)G.xb && (unsigned)ci < (unsigned)G.xc;
+        if constexpr (!R12) rh[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, inside ? g_byte[j] : (int)0x80000000, soff, 0);
       }
     }
   };

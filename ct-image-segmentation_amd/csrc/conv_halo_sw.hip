@@ -122,6 +122,7 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
   };
   const int64_t in_sample = (int64_t)P.Xi * P.Yi * P.Zi, out_sample = (int64_t)P.Xo * P.Yo * P.Zo;
   u32x4 rh[J];
+  // (branch-free raw buffer loads measured no faster here: 0.171 -> 0.182 ms on the 128 -> 32 up pass, 0.094 -> 0.103 on 64 -> 64)
   auto gload = [&](int t) {
     int n, a0, b0, c0;
     tile_origin(t, n, a0, b0, c0);
