@@ -76,7 +76,11 @@ class _NormAct:
         conv feeding this norm) from the same pass."""
         plan, y = self.plan, self.y
         N, S, C = y.dims[0], y.S, y.C
+        # row ranges per sample: 512 rows each on the big levels; on the small ones enough ranges for ~1024 workgroups in all (the
+        # 25 MB bottom-level pass ran 96 workgroups: 70 us, 28 us with 1024; not below 32 rows per range)
         P = max(1, min(1024, math.ceil(S / 512)))
+        if nat.is16(plan.dt):      # (fp32 storage keeps its partition: the 40-step fp32 trajectory test pins a summation order)
+            P = max(P, min(math.ceil(1024 / N), math.ceil(S / 32)))
         ld = rup(C, 4)
         part = torch.zeros((N, P, 3, ld), dtype=torch.float32, device=plan.device)
         sums = torch.zeros((N, C, 2), dtype=torch.float32, device=plan.device)

@@ -81,10 +81,11 @@ __global__ __launch_bounds__(256) void instnorm_prelu_fwd_kernel(const char* __r
                                                                   int res_ld, char* __restrict__ out, int out_ld, int64_t S,
                                                                   int C, int Cv) {
   constexpr int SZ = TT<T>::SZ;   // EPC: elements per chunk (a row is Cv chunks of EPC elements)
-  extern __shared__ float s_mr[];  // [C][2]
+  extern __shared__ float s_mr[];  // per chunk [EPC][2] + 1 pad word (consecutive lanes read consecutive chunks: conflict-free)
+  constexpr int TB = 2 * EPC + 1;
   const int n = blockIdx.y;
   if (mean_rstd != nullptr)
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_mr[i] = mean_rstd[(int64_t)n * C * 2 + i];
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_mr[((i >> 1) / EPC) * TB + ((i >> 1) % EPC) * 2 + (i & 1)] = mean_rstd[(int64_t)n * C * 2 + i];
   __syncthreads();
   const float al = alpha != nullptr ? alpha[0] : 1.f;
   const int64_t total = S * Cv;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_fwd_kernel(const char* __r
       if (c < C) {
         o = x[e];
         if (mean_rstd != nullptr) {
-          o = (o - s_mr[2 * c]) * s_mr[2 * c + 1];
+          o = (o - s_mr[cv * TB + 2 * e]) * s_mr[cv * TB + 2 * e + 1];
           o = o > 0.f ? o : al * o;
         }
         if (res != nullptr) o += r[e];
@@ -138,10 +139,11 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_reduce_kernel(const ch
   // of two <= 64 (wave butterflies first), else one slot per thread.  The footprint matters: this pass shares the CUs with
   // the weight-gradient kernels of the side stream, and at 24 KB per block few of its blocks found room beside them.
   extern __shared__ float s_mr[];
-  float* const s_red = s_mr + 2 * C;
+  constexpr int TB = 2 * EPC + 1;       // (mean, rstd) of a chunk's channels + a pad word: conflict-free across consecutive chunks
+  float* const s_red = s_mr + Cv * TB;
   const bool pow2 = (Cv & (Cv - 1)) == 0 && Cv <= 64;
   const int p = blockIdx.x, n = blockIdx.y;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_mr[i] = mean_rstd[(int64_t)n * C * 2 + i];
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_mr[((i >> 1) / EPC) * TB + ((i >> 1) % EPC) * 2 + (i & 1)] = mean_rstd[(int64_t)n * C * 2 + i];
   __syncthreads();
   const float al = alpha[0];
   const int64_t rows_per = (S + P - 1) / P;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_reduce_kernel(const ch
       for (int e = 0; e < EPC; ++e) {
         const int c = cv * EPC + e;
         if (c < C) {
-          const float xh = (yv[e] - s_mr[2 * c]) * s_mr[2 * c + 1];
+          const float xh = (yv[e] - s_mr[cv * TB + 2 * e]) * s_mr[cv * TB + 2 * e + 1];
           const float dxh = gv[e] * (xh > 0.f ? 1.f : al);
           a1[e] += dxh;
           a2[e] += dxh * xh;
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
                                                                         int pld, const double* __restrict__ da_part, int n_da,
                                                                         float* __restrict__ dalpha) {
   constexpr int SZ = TT<T>::SZ;   // EPC: elements per chunk (a row is Cv chunks of EPC elements)
-  extern __shared__ float s_tab[];  // [C][4]: mean, rstd, s1, s2  (+ [256][EPC] column-sum scratch when COLSUM)
+  extern __shared__ float s_tab[];  // per chunk [EPC][4] + 1 pad: mean, rstd, s1, s2  (+ [256][EPC] column-sum scratch when COLSUM)
   float cs[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) cs[e] = 0.f;
@@ -308,16 +310,22 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
   // the reduce pass that precedes this one streamed (g, y) front to back: walk BACKWARDS (last sample first, last voxel
   // first) so the most recently read part of both tensors is re-read while it still sits in L2 / Infinity Cache
   const int n = gridDim.y - 1 - blockIdx.y;
+  // table layout: the 4 constants of the EPC channels of chunk cv at cv * (4 * EPC + 1): consecutive lanes read consecutive chunks,
+  // and without the pad word their addresses are 4 * EPC floats apart — a 32-way bank conflict on every read at C = 256 (the
+  // 25 MB bottom-level pass took 91 us, the 151 MB level-1 pass 47)
+  constexpr int TB = 4 * EPC + 1;
   for (int i = threadIdx.x; i < C; i += blockDim.x) {
-    s_tab[4 * i] = mean_rstd[((int64_t)n * C + i) * 2];
-    s_tab[4 * i + 1] = mean_rstd[((int64_t)n * C + i) * 2 + 1];
-    s_tab[4 * i + 2] = sums[((int64_t)n * C + i) * 2];
-    s_tab[4 * i + 3] = sums[((int64_t)n * C + i) * 2 + 1];
+    float* t = s_tab + (i / EPC) * TB + (i % EPC) * 4;
+    t[0] = mean_rstd[((int64_t)n * C + i) * 2];
+    t[1] = mean_rstd[((int64_t)n * C + i) * 2 + 1];
+    t[2] = sums[((int64_t)n * C + i) * 2];
+    t[3] = sums[((int64_t)n * C + i) * 2 + 1];
   }
   __syncthreads();
   const float al = alpha[0];
   const int64_t total = S * Cv;
   auto body = [&](int64_t v, int cv) {
+    const float* tab = s_tab + cv * TB;
     const int64_t vox = (int64_t)n * S + v;
     float gv[EPC], yv[EPC], o[EPC];
     load_ep<T, EPC>(g + (vox * g_ld + cv * EPC) * SZ, gv);
@@ -327,10 +335,10 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
       const int c = cv * EPC + e;
       float r = 0.f;
       if (c < C) {
-        const float rstd = s_tab[4 * c + 1];
-        const float xh = (yv[e] - s_tab[4 * c]) * rstd;
+        const float rstd = tab[4 * e + 1];
+        const float xh = (yv[e] - tab[4 * e]) * rstd;
         const float dxh = gv[e] * (xh > 0.f ? 1.f : al);
-        r = rstd * (dxh - s_tab[4 * c + 2] - xh * s_tab[4 * c + 3]);
+        r = rstd * (dxh - tab[4 * e + 2] - xh * tab[4 * e + 3]);
       }
       o[e] = r;
       if (COLSUM) cs[e] += r;
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
   if constexpr (COLSUM) {
     // (gridDim.x * 256) % Cv == 0: thread t handled the same chunk column in every iteration (the sweep runs backwards from
     // total - 1, total = S * Cv); fixed-order sums of the threads of each column
-    float* s_cs = s_tab + 4 * C;
+    float* s_cs = s_tab + Cv * TB;
     const int64_t lead = (int64_t)blockIdx.x * 256;
     if ((Cv & (Cv - 1)) == 0 && Cv <= 64) {
       // power-of-two Cv: lanes l, l + Cv, l + 2 Cv, ... of a wave share the column -> xor butterfly, then 4 waves through LDS
@@ -512,7 +520,7 @@ extern "C" int ctseg_instnorm_prelu_fwd(int32_t dtype, const void* y, int32_t y_
   CHECK_CL_HALF_FWD(dtype, C, y_ld, out_ld, res ? res_ld : y_ld);
   CTSEG_REQUIRE(mean_rstd == nullptr || alpha != nullptr, "instnorm_prelu_fwd: alpha missing");
   dim3 grid(ew_blocks_for(S * Cv, Cv), N);
-  const size_t sh = 2 * C * sizeof(float);
+  const size_t sh = Cv * (2 * EPC_ + 1) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
 #define CTSEG_FWD(T, EP)                                                                                                      \
   hipLaunchKernelGGL((instnorm_prelu_fwd_kernel<T, EP>), grid, dim3(256), sh, st, (const char*)y, y_ld, mean_rstd, alpha,     \
@@ -535,7 +543,7 @@ extern "C" int ctseg_instnorm_prelu_bwd_reduce(int32_t dtype, const void* g, int
   const bool pow2 = (Cv & (Cv - 1)) == 0 && Cv <= 64;
   // reduction scratch: 4 waves x Cv chunks (butterfly path) or one slot per thread; padding it to the old 24 KB measured
   // 12.45 -> 12.49 ms/step (fewer of these blocks fit beside the side stream's weight-gradient workgroups)
-  const size_t sh = (2 * C + (pow2 ? 4 * Cv * 3 * EPC_ : 256 * 3 * EPC_)) * sizeof(float);
+  const size_t sh = (Cv * (2 * EPC_ + 1) + (pow2 ? 4 * Cv * 3 * EPC_ : 256 * 3 * EPC_)) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
 #define CTSEG_RED(T, EP)                                                                                                     \
   hipLaunchKernelGGL((instnorm_prelu_bwd_reduce_kernel<T, EP>), dim3(P, N), dim3(256), sh, st, (const char*)g, g_ld,         \
@@ -584,7 +592,7 @@ static int bwd_apply_launch(int32_t dtype, const void* g, int32_t g_ld, const vo
     CTSEG_REQUIRE(gx >= 1, "instnorm_prelu_bwd_apply_colsum: partial buffer too small for C=%d", C);
   }
   dim3 grid(gx, N);
-  const size_t sh = (4 * C + (colsum ? 256 * EPC_ : 0)) * sizeof(float);
+  const size_t sh = (Cv * (4 * EPC_ + 1) + (colsum ? 256 * EPC_ : 0)) * sizeof(float);       // padded constant table (+ column-sum scratch)
   hipStream_t st = (hipStream_t)stream;
 #define CTSEG_APPLY(T, EP, CS)                                                                                                      \
   hipLaunchKernelGGL((instnorm_prelu_bwd_apply_kernel<T, EP, CS>), grid, dim3(256), sh, st, (const char*)g, g_ld, (const char*)y, y_ld, \
