@@ -209,7 +209,10 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     for (int j = 0; j < APW; ++j) {
       const int ci = (wave + j * NW) * 64 + lane, tv = ci / ACH, ch = ci - tv * ACH;
       const int ix = tv >> 6, iy = (tv >> 3) & 7, iz = tv & 7;
-      apoff[j] = ((ix * P.Yo + iy) * P.Zo + iz) * P.add_ld * 2 + (blockIdx.y * ACH + ch) * 16;
+      // 64-byte voxels (ACH = 4): the 16-byte chunk at LDS position ch holds channel chunk ch ^ ((voxel >> 2) & 3) — the 16 voxels x
+      // 2 halves a 32-lane group reads (8 bytes each, 64 bytes apart) then cover all 64 banks instead of 8 slots four times
+      const int lch = ACH == 4 ? (ch ^ ((tv >> 2) & 3)) : ch;
+      apoff[j] = ((ix * P.Yo + iy) * P.Zo + iz) * P.add_ld * 2 + (blockIdx.y * ACH + lch) * 16;
       aphot[j] = (1u << ix) | (1u << (4 + iy)) | (1u << (12 + iz));
     }
   }
@@ -513,11 +516,13 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
 #pragma unroll
         for (int i = 0; i < X_TX; ++i) cadd[j][i] = *reinterpret_cast<const u32x2*>(hb + cbase + 2 * j * X_PLANE + i * X_XSTRIDE);
     } else if constexpr (ADD == 3) {
-      const char* ab = sA + buf * ABUF + (((2 * yp + pdy) * 8 + pz) * ACH) * 16 + (ns * NT * 16 + 4 * q4) * 2;
+      const int av = (2 * yp + pdy) * 8 + pz, asw = ACH == 4 ? ((av >> 2) & 3) : 0;       // (the swizzle of the DMA source side)
+      const char* ab = sA + buf * ABUF + av * ACH * 16 + (q4 & 1) * 8;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < X_TX; ++i) cadd[j][i] = *reinterpret_cast<const u32x2*>(ab + i * 64 * ACH * 16 + j * 32);
+        for (int i = 0; i < X_TX; ++i)
+          cadd[j][i] = *reinterpret_cast<const u32x2*>(ab + i * 64 * ACH * 16 + (((ns * NT + j) * 2 + (q4 >> 1)) ^ asw) * 16);
     }
   };
 

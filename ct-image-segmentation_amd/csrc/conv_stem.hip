@@ -166,6 +166,8 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
     const bool xok = x0 + wave < P.Xr, zok = z0 + pz < P.Zr;
     char* ob = P.out + vb * P.o_ld * 2;
     char* ob2 = P.out2 != nullptr ? P.out2 + vb * P.o2_ld * 2 : nullptr;
+    const bool wide = NT % 2 == 0 && P.Cn_store == 16 * NT && (P.o_ld & 7) == 0 &&
+                      (P.out2 == nullptr || ((P.out2_col0 & 31) == 0 && (P.o2_ld & 7) == 0)) && P.xcd_order == 0;
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {   // K = 32 is ONE MFMA per 16x16 tile: operand -> MFMA -> store, row tile by row tile
       u32x4 xf;
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
         xf[k] = lo | (hi << 16);
       }
       const bool rv = xok && zok && (y0 + 2 * i + pdy < P.Yr);
+      u32x2 o2[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -186,11 +189,31 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
           v[e] = acc[e] + bias[j][e];
           if (STATS && rv) { wsum[j][e] += v[e]; wsq[j][e] += v[e] * v[e]; }
         }
-        const int ch = j * 16 + 4 * q4;
-        if (rv && ch < P.Cn_store) {
-          char* op = (ob2 != nullptr && ch >= P.out2_col0) ? ob2 + ((int64_t)ovox[i] * P.o2_ld + (ch - P.out2_col0)) * 2
-                                                          : ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2;
-          *reinterpret_cast<u32x2*>(op) = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
+        o2[j] = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
+        if (!wide) {
+          const int ch = j * 16 + 4 * q4;
+          if (rv && ch < P.Cn_store) {
+            char* op = (ob2 != nullptr && ch >= P.out2_col0) ? ob2 + ((int64_t)ovox[i] * P.o2_ld + (ch - P.out2_col0)) * 2
+                                                            : ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2;
+            *reinterpret_cast<u32x2*>(op) = o2[j];
+          }
+        }
+      }
+      if constexpr (NT % 2 == 0) {
+        if (wide) {
+          // 16-byte stores: v_permlane16_swap pairs two 16-column blocks so that a lane holds 8 consecutive channels (chunk
+          // {0, 2, 1, 3}[q4] of the pair's 32 channels): one store instruction writes whole 64-byte rows instead of half rows
+#pragma unroll
+          for (int jp = 0; jp < NT / 2; ++jp) {
+            const auto s0 = __builtin_amdgcn_permlane16_swap(o2[2 * jp][0], o2[2 * jp + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(o2[2 * jp][1], o2[2 * jp + 1][1], false, false);
+            const int ch = jp * 32 + ((q4 & 1) * 2 + (q4 >> 1)) * 8;
+            if (rv) {
+              char* op = (ob2 != nullptr && ch >= P.out2_col0) ? ob2 + ((int64_t)ovox[i] * P.o2_ld + (ch - P.out2_col0)) * 2
+                                                              : ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2;
+              *reinterpret_cast<u32x4*>(op) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            }
+          }
         }
       }
     }
@@ -219,6 +242,7 @@ static int stem_grid(int total) { return total < 1024 ? total : 1024; }
 int conv_stem_slots(const ConvKArgs& a) { return stem_grid(stem_tiles(a.Xr, a.Yr, a.Zr) * a.N); }
 
 void launch_conv_stem(ConvKArgs& a, hipStream_t st) {
+  a.xcd_order = getenv("CTSEG_STEM_STORE_B64") != nullptr;      // timing switch: 8-byte half-row stores (field unused otherwise here)
   StemGeom g;
   g.tiles = stem_tiles(a.Xr, a.Yr, a.Zr); g.tyn = (a.Yr + 7) / 8; g.tzn = (a.Zr + 7) / 8;
   a.tiles = g.tiles;
