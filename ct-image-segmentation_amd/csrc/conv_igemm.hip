@@ -387,7 +387,11 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   const bool stem = !halo && !up && conv_stem_eligible(a, d->dtype, d->nclass);
   const bool sw = !halo && !up && !stem && conv_halo_sw_eligible(a, d->dtype, d->nclass);
   const bool down = !halo && !up && !stem && !sw && conv_down_halo_eligible(a, d->dtype, d->nclass);
-  if (d->stats && down) {
+  const bool downr = !halo && !up && !stem && !sw && !down && conv_down_r_eligible(a, d->dtype, d->nclass);
+  if (d->stats && downr) {
+    CTSEG_REQUIRE(d->stats_tile0 + conv_down_r_slots(a) <= d->stats_tiles && d->stats_ld >= d->Cn,
+                  "conv_igemm: stats partial layout (stride-2 register-weight pass)");
+  } else if (d->stats && down) {
     CTSEG_REQUIRE(d->stats_tile0 + conv_down_halo_slots(a) <= d->stats_tiles && d->stats_ld >= d->Cn,
                   "conv_igemm: stats partial layout (stride-2 halo pass)");
   } else if (d->stats && sw) {
@@ -409,7 +413,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
     CTSEG_REQUIRE(halo || (up && !n_in) || (down && !n_out && !n_add),
                   "conv_igemm: 12-wide bf16 rows are moved by the LDS-halo passes only (ask ctseg_conv_narrow_ok)");
   if (d->out2 != nullptr)
-    CTSEG_REQUIRE((stem || down) && d->add == nullptr && d->out2_col0 > 0 && d->out2_col0 % 4 == 0 && d->out2_col0 < d->Cn_store &&
+    CTSEG_REQUIRE((stem || down || downr) && d->add == nullptr && d->out2_col0 > 0 && d->out2_col0 % 4 == 0 && d->out2_col0 < d->Cn_store &&
                       d->o2_ld >= d->Cn_store - d->out2_col0 && d->o2_ld % 4 == 0 && ((uintptr_t)d->out2 % 16) == 0,
                   "conv_igemm: out2 (split output) is not supported for this pass (ask ctseg_conv_split_ok first)");
   hipStream_t st = (hipStream_t)stream;
@@ -418,6 +422,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   else if (stem) launch_conv_stem(a, st);
   else if (sw) launch_conv_halo_sw(a, d->nclass, st);
   else if (down) launch_conv_down_halo(a, st);
+  else if (downr) launch_conv_down_r(a, st);
   else if (d->dtype == CTSEG_F32) launch_dtype<float>(a, smallc, d->nclass, st);
   else if (d->dtype == CTSEG_F16) launch_dtype<F16>(a, smallc, d->nclass, st);
   else launch_dtype<BF16>(a, smallc, d->nclass, st);
@@ -446,7 +451,8 @@ extern "C" int ctseg_conv_split_ok(const ctseg_conv_desc* d) {
   if (conv_halo_eligible(a, d->dtype, d->nclass) || conv_up_eligible(a, d->dtype, d->nclass)) return 0;
   if (conv_stem_eligible(a, d->dtype, d->nclass)) return 1;
   if (conv_halo_sw_eligible(a, d->dtype, d->nclass)) return 0;
-  return conv_down_halo_eligible(a, d->dtype, d->nclass) ? 1 : 0;
+  if (conv_down_halo_eligible(a, d->dtype, d->nclass)) return 1;
+  return (d->out2_col0 % 16 == 0 && conv_down_r_eligible(a, d->dtype, d->nclass)) ? 1 : 0;
 }
 
 extern "C" int ctseg_conv_in_norm_ok(const ctseg_conv_desc* d) {
@@ -485,6 +491,7 @@ extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
   if (conv_stem_eligible(a, d->dtype, d->nclass)) return conv_stem_slots(a);
   if (conv_halo_sw_eligible(a, d->dtype, d->nclass)) return conv_halo_sw_slots(a);
   if (conv_down_halo_eligible(a, d->dtype, d->nclass)) return conv_down_halo_slots(a);
+  if (conv_down_r_eligible(a, d->dtype, d->nclass)) return conv_down_r_slots(a);
   const int SZq = d->dtype == CTSEG_F32 ? 4 : 2, EPCq = 16 / SZq;
   const bool smallq = (d->Cg % EPCq) != 0 || (d->g_ld % EPCq) != 0 || ((uintptr_t)d->in % 16) != 0;
   const int bm = tile_rows_for(a, d->dtype, smallq, d->nclass);

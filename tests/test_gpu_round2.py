@@ -624,3 +624,26 @@ def test_head_transposed_conv_backward_reads_12_wide_gradient_rows(cout, shape):
     assert rel_err(res[12][0], ref_gx) < 2.5e-2 and rel_err(res[12][1], ref_gw) < 2.5e-2
     assert torch.equal(res[12][0], res[16][0]), "input gradient"
     assert torch.equal(res[12][1], res[16][1]), "weight gradient"
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 16), (1, 18, 40, 24), (1, 64, 64, 8), (1, 8, 24, 96)])
+def test_stride2_conv_32_to_128_with_register_resident_weights(monkeypatch, shape):
+    """conv_down_r_kernel (Conv3d 32 -> 128 k3 s2: the fused [residual | unit0] convolution of the second down block, and the input
+    gradient of the level-1 transposed conv; reference layers: MONAI UNet behind capstone/models/unet.py): forward, input gradient
+    and weight gradient vs torch on the CPU, forward also vs the generic kernel it replaces (same bf16 operands, another sum order).
+    Ragged 8 x 8 faces, each volume axis as the 1-deep tile axis, two samples."""
+    from capstone_amd._native import BF16
+    from helpers import run_conv_module, rel_err
+    torch.manual_seed(shape[1] + shape[3])
+    mod = torch.nn.Conv3d(32, 128, 3, 2, 1)
+    x = torch.randn(shape[0], 32, *shape[1:])
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    ref_y, ref_gx, ref_gw = y.detach().clone(), xr.grad.clone(), mod.weight.grad.detach().clone()
+    yy, gx, gw, _ = run_conv_module(mod, x, gy, BF16, DEV)
+    assert rel_err(yy, ref_y) < 2.5e-2 and rel_err(gx, ref_gx) < 2.5e-2 and rel_err(gw, ref_gw) < 2.5e-2
+    monkeypatch.setenv("CTSEG_NO_DOWN_R", "1")
+    yg, _, _, _ = run_conv_module(mod, x, gy, BF16, DEV)
+    assert rel_err(yy, yg) < 1e-2          # both round fp32 sums of the same products to bf16
