@@ -1,3 +1,5 @@
+"""Times the fused head launch (logits convolution + cross-entropy, ctseg_conv_logits_ce) of the BASELINE shape in isolation.
+Used by tools/ablate_head_ce.sh; honours the CTSEG_* switches of the plan (e.g. CTSEG_NORM_ON_LOAD)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "ct-image-segmentation_amd")):
