@@ -74,6 +74,37 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
   if (t == 0) counter[n] = 0u;
 }
 
+// Single-level finalize for P <= 1024 partial rows (what the per-workgroup slots of the halo kernels produce): one block per (sample,
+// 8 channels) — 16 columns (8 sums, 8 sums of squares) x 16 row lanes; lane r adds rows r, r + 16, ... in fp64, the 16 sub-sums
+// combine in lane order: fixed order, no atomics, and no cross-block hand-off.  The two-level kernel above publishes its group sums
+// with an agent-scope release per block (buffer_wbl2: an L2 write-back walk, serialised per XCD): 64 groups x N samples of them cost
+// 21 us at N = 2 and 262 us at the 48 windows of a sliding-window forward, for 12 MB of partials.
+__global__ __launch_bounds__(256) void instnorm_finalize1_kernel(const float* __restrict__ part, int P, int ld, int col0, int C, double count,
+                                                                 double eps, float* __restrict__ mean_rstd) {
+  __shared__ double s_sub[16][17];
+  const int n = blockIdx.y, c0 = blockIdx.x * 8, t = threadIdx.x;
+  const int col = t & 15, r = t >> 4;                 // col < 8: sum of channel c0 + col; col >= 8: sum of squares of channel c0 + col - 8
+  const int c = c0 + (col & 7);
+  double s = 0.0;
+  if (c < C) {
+    const float* p = part + (int64_t)n * P * 2 * ld + (col >> 3) * ld + col0 + c;
+#pragma unroll 4
+    for (int row = r; row < P; row += 16) s += (double)p[(int64_t)row * 2 * ld];
+  }
+  s_sub[r][col] = s;
+  __syncthreads();
+  if (t < 8 && c0 + t < C) {
+    double sm = 0.0, q = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { sm += s_sub[k][t]; q += s_sub[k][8 + t]; }
+    const double mean = sm / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_rstd[((int64_t)n * C + c0 + t) * 2] = (float)mean;
+    mean_rstd[((int64_t)n * C + c0 + t) * 2 + 1] = (float)(1.0 / sqrt(var + eps));
+  }
+}
+
 template <typename T, int EPC>
 __global__ __launch_bounds__(256) void instnorm_prelu_fwd_kernel(const char* __restrict__ y, int y_ld,
                                                                   const float* __restrict__ mean_rstd,
@@ -505,6 +536,11 @@ extern "C" int ctseg_instnorm_finalize(const float* partials, int32_t N, int32_t
   hipStream_t st = (hipStream_t)stream;
   // scratch: N * FIN_GROUPS * 2 * ld doubles of group sums, followed by N zero-initialised counters (one double slot each)
   unsigned int* counter = reinterpret_cast<unsigned int*>(scratch + (int64_t)N * FIN_GROUPS * 2 * ld);
+  if (P <= 1024 && getenv("CTSEG_FINALIZE_TWO_LEVEL") == nullptr) {
+    hipLaunchKernelGGL(instnorm_finalize1_kernel, dim3((C + 7) / 8, N), dim3(256), 0, st, partials, P, ld, col0, C, count, eps, mean_rstd);
+    CTSEG_LAUNCH_CHECK("instnorm_finalize");
+    return 0;
+  }
   int groups = P / 8;                      // >= 8 partial rows per first-level group
   groups = groups < 1 ? 1 : (groups > FIN_GROUPS ? FIN_GROUPS : groups);
   hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(groups, N), dim3(256), 0, st, partials, P, ld, col0, C, count, eps, scratch,
