@@ -74,14 +74,15 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
   if (t == 0) counter[n] = 0u;
 }
 
-// Single-level finalize for P <= 1024 partial rows (what the per-workgroup slots of the halo kernels produce): one block per (sample,
-// 8 channels) — 16 columns (8 sums, 8 sums of squares) x 16 row lanes; lane r adds rows r, r + 16, ... in fp64, the 16 sub-sums
-// combine in lane order: fixed order, no atomics, and no cross-block hand-off.  The two-level kernel above publishes its group sums
+// Single-level finalize for P <= 8192 partial rows (the per-workgroup slots of the halo kernels: <= 512; the per-tile slots of the
+// generic kernel: a few thousand): one block per (sample, 8 channels) — 16 columns (8 sums, 8 sums of squares) x RL row lanes; lane r
+// adds rows r, r + RL, ... in fp64, the RL sub-sums combine in lane order: fixed order, no atomics, and no cross-block hand-off.  The two-level kernel above publishes its group sums
 // with an agent-scope release per block (buffer_wbl2: an L2 write-back walk, serialised per XCD): 64 groups x N samples of them cost
 // 21 us at N = 2 and 262 us at the 48 windows of a sliding-window forward, for 12 MB of partials.
-__global__ __launch_bounds__(256) void instnorm_finalize1_kernel(const float* __restrict__ part, int P, int ld, int col0, int C, double count,
-                                                                 double eps, float* __restrict__ mean_rstd) {
-  __shared__ double s_sub[16][17];
+template <int RL>      // row lanes: 16 (256 threads) up to 1024 partial rows, 64 (1024 threads) up to 8192
+__global__ __launch_bounds__(16 * RL) void instnorm_finalize1_kernel(const float* __restrict__ part, int P, int ld, int col0, int C, double count,
+                                                                     double eps, float* __restrict__ mean_rstd) {
+  __shared__ double s_sub[RL][17];
   const int n = blockIdx.y, c0 = blockIdx.x * 8, t = threadIdx.x;
   const int col = t & 15, r = t >> 4;                 // col < 8: sum of channel c0 + col; col >= 8: sum of squares of channel c0 + col - 8
   const int c = c0 + (col & 7);
@@ -89,14 +90,14 @@ __global__ __launch_bounds__(256) void instnorm_finalize1_kernel(const float* __
   if (c < C) {
     const float* p = part + (int64_t)n * P * 2 * ld + (col >> 3) * ld + col0 + c;
 #pragma unroll 4
-    for (int row = r; row < P; row += 16) s += (double)p[(int64_t)row * 2 * ld];
+    for (int row = r; row < P; row += RL) s += (double)p[(int64_t)row * 2 * ld];
   }
   s_sub[r][col] = s;
   __syncthreads();
   if (t < 8 && c0 + t < C) {
     double sm = 0.0, q = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { sm += s_sub[k][t]; q += s_sub[k][8 + t]; }
+    for (int k = 0; k < RL; ++k) { sm += s_sub[k][t]; q += s_sub[k][8 + t]; }
     const double mean = sm / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -536,8 +537,9 @@ extern "C" int ctseg_instnorm_finalize(const float* partials, int32_t N, int32_t
   hipStream_t st = (hipStream_t)stream;
   // scratch: N * FIN_GROUPS * 2 * ld doubles of group sums, followed by N zero-initialised counters (one double slot each)
   unsigned int* counter = reinterpret_cast<unsigned int*>(scratch + (int64_t)N * FIN_GROUPS * 2 * ld);
-  if (P <= 1024 && getenv("CTSEG_FINALIZE_TWO_LEVEL") == nullptr) {
-    hipLaunchKernelGGL(instnorm_finalize1_kernel, dim3((C + 7) / 8, N), dim3(256), 0, st, partials, P, ld, col0, C, count, eps, mean_rstd);
+  if (P <= 8192 && getenv("CTSEG_FINALIZE_TWO_LEVEL") == nullptr) {
+    if (P <= 1024) hipLaunchKernelGGL(instnorm_finalize1_kernel<16>, dim3((C + 7) / 8, N), dim3(256), 0, st, partials, P, ld, col0, C, count, eps, mean_rstd);
+    else hipLaunchKernelGGL(instnorm_finalize1_kernel<64>, dim3((C + 7) / 8, N), dim3(1024), 0, st, partials, P, ld, col0, C, count, eps, mean_rstd);
     CTSEG_LAUNCH_CHECK("instnorm_finalize");
     return 0;
   }
