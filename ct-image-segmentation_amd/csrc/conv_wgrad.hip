@@ -345,26 +345,28 @@ __global__ __launch_bounds__(32 * NSUB) void wgrad_reduce_kernel(const float* __
 // combined in fixed order; ceil(rows * ceil(nb / 4) / 8) blocks.  (The scalar kernel above moves 128 B per half wave with 8
 // sub-sums: 1 - 1.5 TB/s on the 30 - 67 MB of slabs of a persistent LDS-halo weight-gradient kernel, 12 + 6 launches per step of
 // the reference's network.)  col0 a multiple of 4; columns nb .. roundup(nb, 4) are pad columns of the slab (read, not written).
+template <int LW, int NSUB>      // LW lanes x float4 along a slab row, NSUB strided sub-sums: (8, 32) for many slabs, (32, 8) for few
 __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ ws, int nslabs, int kpad_w, int cn_pad, int A, int AS, int T,
                                                             int col0, int nb, float* __restrict__ dw, float* __restrict__ db) {
-  __shared__ f32x4 s_part[32][8];
+  static_assert(LW * NSUB == 256, "256 threads");
+  __shared__ f32x4 s_part[NSUB][LW];
   const int nb4 = (nb + 3) >> 2, total4 = (T * AS + 1) * nb4;
   const int64_t slab = (int64_t)kpad_w * cn_pad;
-  const int el = threadIdx.x & 7, sub = threadIdx.x >> 3;
-  const int i4 = blockIdx.x * 8 + el;
+  const int el = threadIdx.x % LW, sub = threadIdx.x / LW;
+  const int i4 = blockIdx.x * LW + el;
   const int k = i4 / nb4, b0 = (i4 - k * nb4) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i4 < total4) {
     const float* p = ws + (int64_t)k * cn_pad + col0 + b0;
 #pragma unroll 4
-    for (int q = sub; q < nslabs; q += 32) s += *reinterpret_cast<const f32x4*>(p + q * slab);
+    for (int q = sub; q < nslabs; q += NSUB) s += *reinterpret_cast<const f32x4*>(p + q * slab);
   }
   s_part[sub][el] = s;
   __syncthreads();
   if (sub == 0 && i4 < total4) {
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 32; ++q) t += s_part[q][el];
+    for (int q = 0; q < NSUB; ++q) t += s_part[q][el];
     if (k == T * AS) {
       if (db != nullptr)
 #pragma unroll
@@ -491,11 +493,15 @@ extern "C" int ctseg_conv_wgrad_reduce(const float* ws, int32_t nslabs, int32_t 
                                        int32_t T, int32_t col0, int32_t nb, float* dw, float* db, void* stream) {
   CTSEG_REQUIRE(ws && dw && nslabs >= 1 && A <= AS && T * AS + 1 <= kpad_w && col0 + nb <= cn_pad, "wgrad_reduce: bad arguments");
   const int64_t total = (int64_t)(T * AS + 1) * nb;
-  if ((col0 & 3) == 0 && (cn_pad & 3) == 0 && col0 + ((nb + 3) & ~3) <= cn_pad && ((uintptr_t)ws & 15) == 0 && nslabs >= 64 &&
+  if ((col0 & 3) == 0 && (cn_pad & 3) == 0 && col0 + ((nb + 3) & ~3) <= cn_pad && ((uintptr_t)ws & 15) == 0 &&
       getenv("CTSEG_WGRAD_REDUCE_SCALAR") == nullptr) {
     const int total4 = (T * AS + 1) * ((nb + 3) / 4);
-    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((total4 + 7) / 8)), dim3(256), 0, (hipStream_t)stream, ws, nslabs, kpad_w, cn_pad, A, AS,
-                       T, col0, nb, dw, db);
+    if (nslabs >= 64)
+      hipLaunchKernelGGL((wgrad_reduce4_kernel<8, 32>), dim3((unsigned)((total4 + 7) / 8)), dim3(256), 0, (hipStream_t)stream, ws, nslabs, kpad_w,
+                         cn_pad, A, AS, T, col0, nb, dw, db);
+    else
+      hipLaunchKernelGGL((wgrad_reduce4_kernel<32, 8>), dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, (hipStream_t)stream, ws, nslabs, kpad_w,
+                         cn_pad, A, AS, T, col0, nb, dw, db);
     CTSEG_LAUNCH_CHECK("wgrad_reduce4");
     return 0;
   }
