@@ -229,16 +229,18 @@ __global__ __launch_bounds__(512) void conv_up_halo_kernel(const ConvKArgs P, in
       }
     };
     using std::integral_constant;
+    // classes that differ in the z parity write z-neighbouring voxels (two 24-byte rows = 48 contiguous bytes): they run back to back
+    // in the same waves so that the two partial writes of a line meet in L2 (15 / 12 taps per wave half instead of 13 / 14)
     if (half == 0) {
       do_class(integral_constant<int, 8>{}, 7);
-      do_class(integral_constant<int, 1>{}, 0);
-      do_class(integral_constant<int, 2>{}, 1);
-      do_class(integral_constant<int, 2>{}, 2);
-    } else {
-      do_class(integral_constant<int, 4>{}, 3);
-      do_class(integral_constant<int, 4>{}, 5);
       do_class(integral_constant<int, 4>{}, 6);
+      do_class(integral_constant<int, 2>{}, 1);
+      do_class(integral_constant<int, 1>{}, 0);
+    } else {
+      do_class(integral_constant<int, 4>{}, 5);
       do_class(integral_constant<int, 2>{}, 4);
+      do_class(integral_constant<int, 4>{}, 3);
+      do_class(integral_constant<int, 2>{}, 2);
     }
   };
 
