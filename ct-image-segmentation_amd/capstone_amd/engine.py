@@ -419,7 +419,7 @@ class GemmLayer:
         bnw = lib.ctseg_wgrad_tile_cols(cn)
         kpad_w, cn_pad = rup(self.T * cg + 1, 128), rup(cn, bnw)
         nwg = (kpad_w // 128) * (cn_pad // bnw) * N
-        splits = max(1, min(math.ceil(2048 / nwg), math.ceil(rows / 512), 1024))
+        splits = max(1, min(math.ceil(int(os.environ.get("CTSEG_WGRAD_TARGET_WGS", "2048")) / nwg), math.ceil(rows / 512), 1024))
         # slabs (N * splits) in multiples of 8: the kernel then keeps all K / column blocks of a slab on one XCD (one L2 fetch
         # of the rows they share instead of one per XCD)
         m = 8 // math.gcd(N, 8)

@@ -314,7 +314,9 @@ class _Level:
         # The head's weight gradients (HBM-bound, 1.2 ms of side-stream work) are not queued beside the head's own HBM-bound
         # input-gradient / norm-backward passes but when the backward reaches level `defer_to`, whose passes are MFMA-bound:
         # same-box 12.48 -> 12.41 ms/step at 2, 12.44 at 1, 12.69 at 3 (the side stream's tail grows).
-        defer_to = int(os.environ.get("CTSEG_DEFER_HEAD_WGRAD", "2"))   # 0 = off
+        # Round 2: with the head's weight gradients at 0.63 ms (x-column reuse, LDS-halo transposed-conv kernel) instead of 1.2 ms the
+        # deferral no longer pays: not deferred 9.69 / 9.70 ms/step, level 1 9.90, level 2 9.79 / 9.83, level 3 10.00 (same box).
+        defer_to = int(os.environ.get("CTSEG_DEFER_HEAD_WGRAD", "0"))   # 0 = off
         if self.is_top and defer_to > 0:
             plan._defer = []
         if depth == defer_to and depth > 0 and getattr(plan, "_stash", None):

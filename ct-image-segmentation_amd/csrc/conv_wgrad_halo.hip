@@ -635,7 +635,9 @@ static int wgrad_halo_grid(const ctseg_wgrad_desc* d) {
   // per CU for the 32->32 layer); the smaller LDS footprint is kept for what it leaves to the main stream's kernels
   int per_cu = (vb + db <= 64) ? 2 : 1;
   if (vb == 32 && db == 32 && getenv("CTSEG_WGRAD_HEAD_OLD") == nullptr && (d->g_ld == 12 || d->g_ld == 16) && (d->d_ld == 12 || d->d_ld == 16))
-    per_cu = wgrad_head2(d) ? 2 : 4;      // 27 KB of LDS, 128 registers: four 4-wave or two 8-wave workgroups per CU
+    per_cu = wgrad_head2(d) ? 1 : 4;      // 27 KB of LDS, 128 registers: four 4-wave or two 8-wave workgroups per CU would fit.
+  // ONE 8-wave workgroup per CU for the head kernel: alone it is slower that way (0.43 -> 0.50 ms), inside the step — it runs on the
+  // side stream beside the main stream's HBM-bound head passes — faster: 9.94 / 9.90 -> 9.86 / 9.82 ms/step (same box, round 2)
   if (const char* e = getenv("CTSEG_WH_PER_CU")) per_cu = atoi(e);
   int g = 256 * per_cu;
   return g < tiles ? g : tiles;
