@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
   constexpr int CE_T = CE ? NW * 2 * 16 * 48 : 0;           // per-wave exchange scratch: 12 fp32 logits per voxel, two x planes at a time
   constexpr int CE_B = CE ? 3 * 16 * 4 + NW * 2 * 8 : 0;     // Dice counters, per-wave loss sums
   constexpr int NRM_B = R12 ? X_NRM_MAXN * 96 : 0;           // operand normalisation: per sample 3 channel quads x (mean x 4, rstd x 4)
-  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B + 2 * ABUF + NRM_B];
+  constexpr int CE_L = CE ? NW * 3 * 6 * 64 * 4 : 0;         // per-LANE Dice counters: [wave][kind][class pair][lane], two 16-bit fields per word
+  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B + 2 * ABUF + NRM_B + CE_L];
+  char* const sLaneBase = smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B + 2 * ABUF + NRM_B;
   char* const sA = smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B;
   float* const sPar = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B + 2 * ABUF);
   char* const sW = smem + 2 * CF::HALO;
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned int* const sLane = reinterpret_cast<unsigned int*>(sLaneBase) + wave * (3 * 6 * 64) + lane;     // (CE only)
   const int yp = wave & 3, ns = wave >> 2;               // y pair of the column, wave group
   const int r16 = lane & 15, q4 = lane >> 4;
   const ctseg_conv_class& K = P.cls[0];
@@ -531,28 +534,29 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
   // Dice counters (|pred & true|, |pred|, |true| per class): per LANE, two 16-bit fields per register (class c in word c / 2), one
   // voxel per lane and tile, flushed at every sample change (a field holds 65 535 tiles of one workgroup and sample).  (Wave ballots per class put ~100 scalar instructions per tile on
   // the CU's single scalar unit: 0.36 ms of this launch on a net whose predictions are not yet all background.)
-  uint32_t p_cnt[3][6];
+  // ... kept in LDS, one word per (kind, class pair) and lane, updated with returnless ds_add_u32 (three per voxel): as per-lane
+  // REGISTER fields the update was a dynamic index into 18 registers = ~60 compare / select / add instructions per voxel, 0.16 ms of
+  // this launch on data where most waves hold foreground (the synthetic batch of the bench; real CT labels mostly take the
+  // all-background shortcut below)
+  if constexpr (CE) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
-#pragma unroll
-    for (int w = 0; w < 6; ++w) p_cnt[k][w] = 0u;
+    for (int k = 0; k < 18; ++k) sLane[k * 64] = 0u;
+  }
   unsigned int u_bg = 0u;                  // wave-uniform: voxels of all-background waves (they count for class 0 in all three kinds)
-  auto cnt_flush = [&]() {                // per-lane byte fields -> wave sums -> the workgroup's LDS counters
+  auto cnt_flush = [&]() {                // per-lane fields -> wave sums -> the workgroup's LDS counters
     if (lane == 0 && u_bg != 0u) { atomicAdd(&sCnt[0], u_bg); atomicAdd(&sCnt[16], u_bg); atomicAdd(&sCnt[32], u_bg); }
     u_bg = 0u;
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
       for (int c = 0; c < 12; ++c) {
-        unsigned int v = (p_cnt[k][c >> 1] >> ((c & 1) * 16)) & 0xffffu;
+        unsigned int v = (sLane[(k * 6 + (c >> 1)) * 64] >> ((c & 1) * 16)) & 0xffffu;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == 0 && v != 0u) atomicAdd(&sCnt[k * 16 + c], v);
       }
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int w = 0; w < 6; ++w) p_cnt[k][w] = 0u;
+    for (int k = 0; k < 18; ++k) sLane[k * 64] = 0u;
   };
   int ce_n = -1;
   auto ce_flush = [&](int n) {            // this workgroup's record of sample n (slot blockIdx.x) and its Dice counts
@@ -675,13 +679,10 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
       if (!(X_ABL & 32)) u_bg += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(valid));
     } else if (valid) {
       const uint32_t it = 1u << ((t & 1) * 16), ip = 1u << ((pred & 1) * 16);
-      const int wt = t >> 1, wp = pred >> 1;
-#pragma unroll
-      for (int wq = 0; wq < 6; ++wq) {
-        p_cnt[2][wq] += (wt == wq) ? it : 0u;
-        p_cnt[1][wq] += (wp == wq) ? ip : 0u;
-        p_cnt[0][wq] += (wp == wq && pred == t) ? ip : 0u;
-      }
+      const int wt = t < 12 ? (t >> 1) : 5, wp = pred >> 1;       // (labels are < C <= 12: host-checked; clamp keeps the address in range)
+      atomicAdd(&sLane[(2 * 6 + wt) * 64], t < 12 ? it : 0u);
+      atomicAdd(&sLane[(1 * 6 + wp) * 64], ip);
+      if (pred == t) atomicAdd(&sLane[wp * 64], ip);
     }
     const float ce_scale = E.coef[(int64_t)o.n * E.coef_stride] * w;
     float d[12];
