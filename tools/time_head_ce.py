@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(SEED)
 m = BaseUNet3D(filters=list(FILTERS), loss_fx=["CrossEntropy"], precision="bf16").to(dev)
 batch = synthetic_batch(2, 512, 512, 48, dev, SEED)
-m.fit_step(batch, keep_logits=False); m.fit_step(batch, keep_logits=False)
+for _ in range(int(os.environ.get("CTSEG_HEADCE_WARM", "2"))): m.fit_step(batch, keep_logits=False)
 plan = m.unet.engine().last_plan
 le = plan._ctseg_loss
 slots = plan.head_ce_slots(10)
