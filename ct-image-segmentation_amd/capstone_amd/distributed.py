@@ -3,9 +3,10 @@
 The reference has no distributed code of its own; multi-GPU is Lightning's DDP (gradient MEAN over
 ranks, bucketed NCCL all-reduce overlapped with backward) reached through Trainer flags
 (capstone/volumetric/base_trainer.py:196,217).  Here the whole gradient is one flat fp32 buffer laid
-out in gradient-readiness order, so the exchange is two collectives per step, not one per tensor:
+out in gradient-readiness order, so the exchange is three collectives per step, not one per tensor:
 chunk 1 (decoder + bottleneck, ~76 % of the bytes) is launched as soon as the bottleneck's weight
-gradient retires and overlaps the encoder backward; chunk 2 (encoder) goes after the stem.  The 1/world
+gradient retires and overlaps the encoder backward; chunk 2 (the deeper encoder levels, up to >= 92 %) overlaps the
+level-0 backward; only the last few per cent (level 0 + stem) go behind the backward.  The 1/world
 factor is folded into the Adam kernel's ``grad_scale`` (no extra pass).  Samples are independent
 (InstanceNorm is per sample), so there is no other data-path collective.
 """
@@ -35,20 +36,28 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
-def split_points(ready_marks, sizes, n_total, first_fraction=0.6):
+def split_points(ready_marks, sizes, n_total, fractions=(0.6, 0.92)):
     """ready_marks: [(program index, [flat offsets that became final])], sizes: {offset: numel}.
     Returns [(program index, end offset)] — after ``program index`` ops of backward the flat gradient is
-    final on [0, end).  Picks the earliest mark whose ready prefix covers ``first_fraction`` of the buffer."""
+    final on [0, end).  For every fraction, the earliest mark whose ready prefix covers that share of the buffer (and
+    extends the previous split): the first collective overlaps the encoder backward, the second leaves only the last few
+    per cent (level 0 + stem) for the exposed collective behind the backward."""
     done, prefix, out = set(), 0, []
     order = sorted(sizes)
     pos = 0
+    fi = 0
     for idx, offs in ready_marks:
         done.update(offs)
         while pos < len(order) and order[pos] in done:
             prefix = order[pos] + sizes[order[pos]]
             pos += 1
-        if not out and prefix >= first_fraction * n_total and prefix < n_total:
-            out.append((idx, prefix))
+        while fi < len(fractions) and prefix >= fractions[fi] * n_total:
+            if prefix < n_total and (not out or prefix > out[-1][1]):
+                if out and out[-1][0] == idx:
+                    out[-1] = (idx, prefix)
+                else:
+                    out.append((idx, prefix))
+            fi += 1
     return out
 
 

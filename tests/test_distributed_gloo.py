@@ -69,6 +69,11 @@ def test_split_points_follow_readiness_prefix():
     pts = cdist.split_points([(2, [0]), (5, [20]), (6, [10]), (9, [80])], sizes, 100)
     assert pts == [(6, 80)]
     assert cdist.split_points([(1, [0, 10, 20, 80])], sizes, 100) == []    # everything at once: one collective at the end
+    # a second split where >= 92 % is final before the end of the backward: only the last few per cent stay for the exposed collective
+    sizes20 = {5 * i: 5 for i in range(20)}
+    assert cdist.split_points([(i, [5 * i]) for i in range(20)], sizes20, 100) == [(11, 60), (18, 95)]
+    # both fractions reached by the same mark: one split there
+    assert cdist.split_points([(3, [0, 10, 20]), (9, [80])], sizes, 100) == [(3, 80)]
 
 
 def test_world1_is_a_no_op():
