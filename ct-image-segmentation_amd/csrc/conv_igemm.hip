@@ -12,6 +12,8 @@
 // so each lane ends up with 4 consecutive output channels of one voxel -> channels-last epilogue.
 // Epilogue: + bias, per-(tile, channel) sum / sum-of-squares partials for InstanceNorm, transpose
 // through LDS, optional addend (residual / gradient accumulation), 16-byte coalesced stores.
+#include <utility>
+
 #include "conv_common.h"
 
 namespace ctseg {
@@ -298,6 +300,11 @@ template <typename T> static int launch_dtype(ConvKArgs& a, bool smallc, int ncl
   // XCD-contiguous tile ranges: measured neutral for single-class passes (their halo re-reads already hit L2 / Infinity Cache),
   // 7-9 % on the 8-class passes (384->64 and 256->64), where every class re-gathers the same input tile
   a.xcd_order = nclass > 1 ? 1 : 0;
+  // classes ride on grid.z, dispatched in index order: longest K loop (most taps) first, so the tail of the launch is made of the
+  // 1-tap classes' short workgroups instead of the 8-tap class's long ones
+  if (nclass > 1 && getenv("CTSEG_CLASS_ORDER_KEEP") == nullptr)
+    for (int i = 1; i < nclass; ++i)
+      for (int j = i; j > 0 && a.cls[j].ntaps > a.cls[j - 1].ntaps; --j) std::swap(a.cls[j], a.cls[j - 1]);
   if constexpr (TT<T>::SZ == 2) {
     if (bm == 192) {
       if (conv_ring_eligible(a, TT<T>::DT, nclass)) { launch_conv_ring(a, nclass, st); return 0; }
