@@ -9,12 +9,20 @@
 //   wgrad   : R[t][b] = sum_v in[2v + t - 1] * dy[v][b],  R[27][b] = sum_v dy[v][b]   -> 4 slabs per workgroup
 #include "conv_common.h"
 
+#ifndef STEM_ABL
+#define STEM_ABL 0     // timing-only ablation bits (tools/ablate_stem.sh): 1 no MFMAs, 2 no LDS operand reads, 4 no patch loads, 8 no stores, 16 no stats
+#endif
+
 namespace ctseg {
 
 constexpr int S_IX = 9, S_IY = 17, S_IZ = 17, S_PZ = 18;          // input patch and its padded z pitch
-constexpr int S_IN = S_IX * S_IY * S_IZ;                           // 2601 elements
-constexpr int S_INB = (S_IX * S_IY * S_PZ * 2 + 15) / 16 * 16;       // bytes of the LDS image, 16-byte aligned (5520)
-constexpr int S_J = (S_IN + 255) / 256;                            // 11 staging slots per thread
+constexpr int S_INB = (S_IX * S_IY * S_PZ * 2 + 2 + 15) / 16 * 16;   // bytes of the LDS image (+ the one-element shift), 16-byte aligned
+// The patch is staged in ALIGNED 4-byte pairs: z runs from 2 z0 - 2 (one element before the first tap's, even) for 18 elements =
+// 9 dwords = the padded pitch.  A pair is inside or outside the volume as a whole (Zi is even), so one bounds test and one load
+// move two elements: 6 loads per thread and tile instead of 11.  Readers see the image through a pointer advanced by one element.
+constexpr int S_DW = S_PZ / 2, S_NDW = S_IX * S_IY * S_DW;          // 1377 dwords
+constexpr int S_J = (S_NDW + 255) / 256;                           // 6 staging slots per thread
+constexpr int S_SHIFT = 2;                                         // byte offset of patch element (0,0,0) inside the image
 
 __device__ __forceinline__ void stem_patch_voxel(int r16, int& dy, int& z) {
   dy = (0xEF80u >> r16) & 1;
@@ -32,27 +40,28 @@ struct StemStage {
 #pragma unroll
     for (int j = 0; j < S_J; ++j) {
       const int idx = tid + j * 256;
-      const int ix = idx / (S_IY * S_IZ), rem = idx - ix * (S_IY * S_IZ), iy = rem / S_IZ, iz = rem - iy * S_IZ;
-      g_off[j] = ((ix - 1) * Yi + (iy - 1)) * Zi + (iz - 1);
-      g_xyz[j] = idx < S_IN ? (ix | (iy << 8) | (iz << 16)) : 0x7f7f7f;
-      g_lds[j] = ((ix * S_IY + iy) * S_PZ + iz) * 2;
+      const int row = idx / S_DW, dw = idx - row * S_DW, ix = row / S_IY, iy = row - ix * S_IY;
+      g_off[j] = ((ix - 1) * Yi + (iy - 1)) * Zi + 2 * dw - 2;
+      g_xyz[j] = idx < S_NDW ? (ix | (iy << 8) | ((2 * dw) << 16)) : 0x7f7f7f;
+      g_lds[j] = ((ix * S_IY + iy) * S_PZ + 2 * dw) * 2;
     }
   }
   __device__ __forceinline__ void load(const unsigned short* base, int x0, int y0, int z0, int Xi, int Yi, int Zi,
-                                       unsigned short (&r)[S_J]) const {
+                                       uint32_t (&r)[S_J]) const {
     // base = element pointer of input voxel (2x0, 2y0, 2z0) of the sample
 #pragma unroll
     for (int j = 0; j < S_J; ++j) {
-      const int xi = 2 * x0 - 1 + (g_xyz[j] & 0xff), yi = 2 * y0 - 1 + ((g_xyz[j] >> 8) & 0xff), zi = 2 * z0 - 1 + (g_xyz[j] >> 16);
-      unsigned short v = 0;
-      if ((unsigned)xi < (unsigned)Xi && (unsigned)yi < (unsigned)Yi && (unsigned)zi < (unsigned)Zi) v = base[g_off[j]];
+      const int xi = 2 * x0 - 1 + (g_xyz[j] & 0xff), yi = 2 * y0 - 1 + ((g_xyz[j] >> 8) & 0xff), zi = 2 * z0 - 2 + (g_xyz[j] >> 16);
+      uint32_t v = 0;
+      if (!(STEM_ABL & 4) && (unsigned)xi < (unsigned)Xi && (unsigned)yi < (unsigned)Yi && (unsigned)zi < (unsigned)Zi)
+        v = *reinterpret_cast<const uint32_t*>(base + g_off[j]);
       r[j] = v;
     }
   }
-  __device__ __forceinline__ void store(char* lds, const unsigned short (&r)[S_J]) const {
+  __device__ __forceinline__ void store(char* lds, const uint32_t (&r)[S_J]) const {
 #pragma unroll
     for (int j = 0; j < S_J; ++j)
-      if ((g_xyz[j] & 0xff) != 0x7f) *reinterpret_cast<unsigned short*>(lds + g_lds[j]) = r[j];
+      if ((g_xyz[j] & 0xff) != 0x7f) *reinterpret_cast<uint32_t*>(lds + g_lds[j]) = r[j];
   }
 };
 
@@ -106,26 +115,27 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
   auto in_base = [&](int n, int x0, int y0, int z0) {
     return reinterpret_cast<const unsigned short*>(P.in) + (((int64_t)n * P.Xi + 2 * x0) * P.Yi + 2 * y0) * P.Zi + 2 * z0;
   };
-  float wsum[NT][4], wsq[NT][4];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 wsum2[NT][2], wsq2[NT][2];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { wsum[j][e] = 0.f; wsq[j][e] = 0.f; }
+    for (int e = 0; e < 2; ++e) { wsum2[j][e] = f32x2{0.f, 0.f}; wsq2[j][e] = f32x2{0.f, 0.f}; }
   int stat_n = -1;
   auto flush_stats = [&](int n) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float a = wsum[j][e], b = wsq[j][e];
+        float a = wsum2[j][e >> 1][e & 1], b = wsq2[j][e >> 1][e & 1];
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
         if (r16 == 0) {
           sStats[(wave * 2 + 0) * BN + j * 16 + 4 * q4 + e] = a;
           sStats[(wave * 2 + 1) * BN + j * 16 + 4 * q4 + e] = b;
         }
-        wsum[j][e] = 0.f;
-        wsq[j][e] = 0.f;
+        wsum2[j][e >> 1][e & 1] = 0.f;
+        wsq2[j][e >> 1][e & 1] = 0.f;
       }
     __syncthreads();
     if (tid < 2 * BN) {
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
     __syncthreads();
   };
 
-  unsigned short rg[S_J];
+  uint32_t rg[S_J];
   int t = blockIdx.x, cur = 0;
   {
     int n, x0, y0, z0;
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
       if (stat_n >= 0) flush_stats(stat_n);
       stat_n = n;
     }
-    const char* h = smem + cur * S_INB;
+    const char* h = smem + cur * S_INB + S_SHIFT;
     const int64_t vb = (((int64_t)n * P.Xo + x0) * P.Yo + y0) * P.Zo + z0;
     const bool xok = x0 + wave < P.Xr, zok = z0 + pz < P.Zr;
     char* ob = P.out + vb * P.o_ld * 2;
@@ -173,6 +183,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
       u32x4 xf;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+        if (STEM_ABL & 2) { xf[k] = (uint32_t)(abase[i] + k + t); continue; }
         const uint32_t lo = toff[2 * k] >= 0 ? *reinterpret_cast<const unsigned short*>(h + abase[i] + toff[2 * k]) : 0u;
         const uint32_t hi = toff[2 * k + 1] >= 0 ? *reinterpret_cast<const unsigned short*>(h + abase[i] + toff[2 * k + 1]) : 0u;
         xf[k] = lo | (hi << 16);
@@ -181,13 +192,14 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
       u32x2 o2[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        mma16<H>(acc, wf[j], xf);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[e] + bias[j][e];
-          if (STATS && rv) { wsum[j][e] += v[e]; wsq[j][e] += v[e] * v[e]; }
+        f32x4 acc = f32x4{bias[j][0], bias[j][1], bias[j][2], bias[j][3]};     // the bias rides in the accumulator
+        if (STEM_ABL & 1) acc = f32x4{__uint_as_float(xf[0] ^ wf[j][0]), __uint_as_float(xf[1]), __uint_as_float(xf[2]), __uint_as_float(xf[3])};
+        else mma16<H>(acc, wf[j], xf);
+        const float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+        if (STATS && !(STEM_ABL & 16) && rv) {      // two-wide fp32 adds / FMAs (v_pk_add_f32, v_pk_fma_f32)
+          const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+          wsum2[j][0] += lo; wsum2[j][1] += hi;
+          wsq2[j][0] = lo * lo + wsq2[j][0]; wsq2[j][1] = hi * hi + wsq2[j][1];
         }
         o2[j] = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
         if (!wide) {
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
             const auto s0 = __builtin_amdgcn_permlane16_swap(o2[2 * jp][0], o2[2 * jp + 1][0], false, false);
             const auto s1 = __builtin_amdgcn_permlane16_swap(o2[2 * jp][1], o2[2 * jp + 1][1], false, false);
             const int ch = jp * 32 + ((q4 & 1) * 2 + (q4 >> 1)) * 8;
-            if (rv) {
+            if ((STEM_ABL & 8) ? (rv && s0[0] == 0x12345678u) : rv) {
               char* op = (ob2 != nullptr && ch >= P.out2_col0) ? ob2 + ((int64_t)ovox[i] * P.o2_ld + (ch - P.out2_col0)) * 2
                                                               : ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2;
               *reinterpret_cast<u32x4*>(op) = u32x4{s0[0], s1[0], s0[1], s1[1]};
@@ -226,6 +238,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const ConvKArgs P, i
 
 bool conv_stem_eligible(const ConvKArgs& a, int dtype, int nclass) {
   if (!is16(dtype) || nclass != 1 || a.Cg != 1 || a.g_ld != 1 || a.sin != 2 || a.sout != 1 || a.out_f32 || a.add) return false;
+  if (((uintptr_t)a.in % 4) != 0) return false;       // the patch is staged in aligned 4-byte pairs
   if (a.cls[0].ntaps != 27 || a.cls[0].kpad != 64 || a.Cn > 64 || a.Cn % 16 != 0 || a.Zr < 4) return false;
   if (a.Xi != 2 * a.Xr || a.Yi != 2 * a.Yr || a.Zi != 2 * a.Zr) return false;
   if ((int64_t)a.Xi * a.Yi * a.Zi >= (1ll << 31) || (int64_t)a.Xo * a.Yo * a.Zo * a.o_ld * 2 >= (1ll << 31)) return false;
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArg
     const int ty = r % P.G.tyn; const int tx = r / P.G.tyn;
     x0 = tx * 4; y0 = ty * 8; z0 = tz * 8;
   };
-  unsigned short rg[S_J];
+  uint32_t rg[S_J];
   u32x4 rd[JD];
   auto gload = [&](int t) {
     int n, x0, y0, z0;
@@ -349,8 +362,8 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArg
   for (; t < total_tiles; t += gridDim.x) {
     const int tn = t + gridDim.x;
     if (tn < total_tiles) gload(tn);
-    const char* xs = smem + cur * BUF;
-    const char* ds = xs + S_INB;
+    const char* xs = smem + cur * BUF + S_SHIFT;
+    const char* ds = xs - S_SHIFT + S_INB;
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       const int s = 2 * wave + ss, x = s >> 1, yb = 4 * (s & 1);
@@ -399,6 +412,7 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArg
 bool wgrad_stem_eligible(const ctseg_wgrad_desc* d) {
   if (d->dtype != CTSEG_BF16 || d->ntaps != 27 || d->sin != 2 || d->Cg != 1 || d->g_ld != 1) return false;
   if (d->Cn > 64 || d->Cn % 16 != 0 || d->d_ld % 8 != 0 || d->d_ld < d->Cn || ((uintptr_t)d->dy % 16) != 0) return false;
+  if (((uintptr_t)d->in % 4) != 0) return false;      // the patch is staged in aligned 4-byte pairs
   if (d->Xi != 2 * d->Xr || d->Yi != 2 * d->Yr || d->Zi != 2 * d->Zr || d->Zr < 4) return false;
   if (d->kpad_w < 32 || d->cn_pad < d->Cn) return false;
   if ((int64_t)d->Xi * d->Yi * d->Zi >= (1ll << 31) || (int64_t)d->Xr * d->Yr * d->Zr * d->d_ld * 2 >= (1ll << 31)) return false;
