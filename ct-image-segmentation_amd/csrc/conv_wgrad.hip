@@ -23,6 +23,7 @@ struct WgradKArgs {
   int kpad_w, cn_pad, d_valid;
   int sx, sy, sz;  // mixed-radix decomposition of a 32-row step
   int kblocks, cblocks;   // > 0: 1-D grid, workgroup -> (K block, column block, slab) decoded so that one XCD owns a slab
+  int addr64;             // 1: a sample of the gathered operand is >= 2 GiB (or CTSEG_WGRAD_ADDR64): 64-bit address chain per chunk
   int taps[CTSEG_MAX_TAPS];
 };
 
@@ -32,6 +33,20 @@ struct WgradKArgs {
 // fetches) and in the read address: 256-byte rows: slot ^ (row & 7); 128-byte rows: slot ^ ((row >> 1) & 3).
 __device__ __attribute__((aligned(16))) unsigned short g_wg_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 __device__ __attribute__((aligned(16))) unsigned short g_wg_one16[8] = {0x3f80, 0, 0, 0, 0, 0, 0, 0};   // bf16 1.0 on channel 0
+
+typedef int32_t wg_i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t __attribute__((address_space(3)))* wg_lds_u32_ptr;
+__device__ void wg_raw_buffer_load_lds(wg_i32x4 rsrc, wg_lds_u32_ptr lds, int size, int voffset, int soffset, int offset,
+                                       int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+__device__ __forceinline__ wg_i32x4 wg_make_rsrc(const void* p, uint32_t bytes) {
+  struct __attribute__((packed)) { const void* ptr; uint32_t range; uint32_t config; } r{p, bytes, 0x00020000u};
+  wg_i32x4 v = __builtin_bit_cast(wg_i32x4, r);
+  v[0] = __builtin_amdgcn_readfirstlane(v[0]);
+  v[1] = __builtin_amdgcn_readfirstlane(v[1]);
+  v[2] = __builtin_amdgcn_readfirstlane(v[2]);
+  v[3] = __builtin_amdgcn_readfirstlane(v[3]);
+  return v;
+}
 
 template <typename T, int BNW, bool SMALLC> struct WgradCfg {
   static constexpr int SZ = TT<T>::SZ;
@@ -181,6 +196,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
   const int d_row0 = tid / DCPR, d_pos = tid % DCPR;
   const int d_c32 = (BNW == 128) ? ((d_pos >> 1) ^ (d_row0 & 7)) : ((d_pos >> 1) ^ ((d_row0 >> 1) & 3));
   const int d_chunk = (d_c32 << 1) | (d_pos & 1);
+  // GLDS addressing without multiplies (the 64-bit voxel -> byte chain of gload() above is ~12 quarter-rate multiplies per chunk and
+  // stage; with two chunks and 16 MFMAs per stage the address code, not the matrix pipe, bounded the kernel at ~30 % MFMA):
+  // a chunk keeps its row's SCALED coordinates (x sin, y sin, z sin), its 32-bit byte offset inside the sample and advances all
+  // four by uniform per-stage constants plus two carry corrections.  Samples >= 2 GiB keep the 64-bit chain (P.addr64).
+  const int gl = P.g_ld * SZ;
+  const char* inb = P.in + (int64_t)n * P.Xi * P.Yi * P.Zi * gl;
+  const int zrs = P.Zr * P.sin, yrs = P.Yr * P.sin;                         // scaled extents of the row grid
+  const int szs = P.sz * P.sin, sys_ = P.sy * P.sin, sxs = P.sx * P.sin;    // scaled 32-row step
+  const int o_step = (szs + (sys_ + sxs * P.Yi) * P.Zi) * gl;               // byte step of 32 rows without carries
+  const int o_cz = P.sin * gl * (P.Zi - P.Zr), o_cy = P.sin * gl * P.Zi * (P.Yi - P.Yr);   // a z carry / a y carry
+  int aoff[AJ];
+  if constexpr (GLDS) {       // (this path keeps the rows' SCALED coordinates in cx / cy / cz)
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      cx[j] *= P.sin; cy[j] *= P.sin; cz[j] *= P.sin;
+      aoff[j] = (((cx[j] + dx) * P.Yi + cy[j] + dy_) * P.Zi + cz[j] + dz) * gl + ci * SZ;
+    }
+  }
+  const bool dcol_ok = col0 + d_chunk * EPC < P.d_valid;
+  int doff = (d_row0 * P.d_ld + d_chunk * EPC) * SZ;                     // byte offset of this thread's first dy chunk in the stage
+  const char* dstage = dbase + (int64_t)mstart * P.d_ld * SZ;              // (uniform) first row of the split
+  const int d_step = 32 * P.d_ld * SZ, d_jstep = (256 / DCPR) * P.d_ld * SZ;
   auto gload_lds = [&](int s, int buf) {
     const int mb = mstart + s * 32;
     char* a = smem + buf * CF::STAGE + wave * 1024;
@@ -189,27 +226,63 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
     for (int j = 0; j < AJ; ++j) {
       const int m = mb + arow0 + j * ARS;
       const char* src = reinterpret_cast<const char*>(g_wg_zero16);
+      const int xi = cx[j] + dx, yi = cy[j] + dy_, zi = cz[j] + dz;
+      const bool inside = (unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi;
       if (m < mend) {
         if (kvalid) {
-          const int xi = cx[j] * P.sin + dx, yi = cy[j] * P.sin + dy_, zi = cz[j] * P.sin + dz;
-          if ((unsigned)xi < (unsigned)P.Xi && (unsigned)yi < (unsigned)P.Yi && (unsigned)zi < (unsigned)P.Zi)
-            src = P.in + ((((nbase + xi) * P.Yi + yi) * P.Zi + zi) * P.g_ld + ci) * SZ;
+          if (inside) src = P.addr64 ? P.in + ((((nbase + xi) * P.Yi + yi) * P.Zi + zi) * P.g_ld + ci) * SZ : inb + (uint32_t)aoff[j];
         } else if (kones) {
           src = reinterpret_cast<const char*>(g_wg_one16);
         }
       }
+      cz[j] += szs;
+      const bool carry_z = cz[j] >= zrs;
+      cz[j] -= carry_z ? zrs : 0;
+      cy[j] += sys_ + (carry_z ? P.sin : 0);
+      const bool carry_y = cy[j] >= yrs;
+      cy[j] -= carry_y ? yrs : 0;
+      cx[j] += sxs + (carry_y ? P.sin : 0);
+      aoff[j] += o_step + (carry_z ? o_cz : 0) + (carry_y ? o_cy : 0);
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a + j * (ARS * PA)), 16, 0, 0);
-      cz[j] += P.sz; if (cz[j] >= P.Zr) { cz[j] -= P.Zr; ++cy[j]; }
-      cy[j] += P.sy; if (cy[j] >= P.Yr) { cy[j] -= P.Yr; ++cx[j]; }
-      cx[j] += P.sx;
     }
 #pragma unroll
     for (int j = 0; j < DJ; ++j) {
       const int m = mb + d_row0 + j * (256 / DCPR);
-      const char* src = reinterpret_cast<const char*>(g_wg_zero16);
-      if (m < mend && col0 + d_chunk * EPC < P.d_valid) src = dbase + ((int64_t)m * P.d_ld + d_chunk * EPC) * SZ;
+      const char* src = (m < mend && dcol_ok) ? dstage + (uint32_t)(doff + j * d_jstep) : reinterpret_cast<const char*>(g_wg_zero16);
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(d + j * 4096), 16, 0, 0);
     }
+    doff += d_step;
+  };
+  // The same stage through range-checked buffer loads (every K block but the one holding the all-ones bias row, samples < 2 GiB):
+  // a voxel outside the volume, a row past the split or a column past d_valid is an out-of-range offset (the hardware delivers
+  // zeros) -- no zero page, no 64-bit pointer arithmetic, one select per chunk.
+  const bool use_buf = GLDS && !P.addr64 && !(kblock * 128 <= ktot && ktot < kblock * 128 + 128);
+  const wg_i32x4 rsA = wg_make_rsrc(inb, (uint32_t)((int64_t)P.Xi * P.Yi * P.Zi * gl));
+  const wg_i32x4 rsD = wg_make_rsrc(dstage, (uint32_t)((int64_t)(mend > mstart ? mend - mstart : 0) * P.d_ld * SZ));
+  int doffb = dcol_ok ? doff : (int)0x80000000;          // (stays out of range: rows * row bytes < 2^31)
+  auto gload_lds_buf = [&](int s, int buf) {
+    const int mb = mstart + s * 32;
+    char* a = smem + buf * CF::STAGE + wave * 1024;
+    char* d = smem + buf * CF::STAGE + 32 * PA + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int m = mb + arow0 + j * ARS;
+      const bool ok = m < mend && kvalid && (unsigned)(cx[j] + dx) < (unsigned)P.Xi && (unsigned)(cy[j] + dy_) < (unsigned)P.Yi &&
+                      (unsigned)(cz[j] + dz) < (unsigned)P.Zi;
+      const int vo = ok ? aoff[j] : (int)0x80000000;
+      cz[j] += szs;
+      const bool carry_z = cz[j] >= zrs;
+      cz[j] -= carry_z ? zrs : 0;
+      cy[j] += sys_ + (carry_z ? P.sin : 0);
+      const bool carry_y = cy[j] >= yrs;
+      cy[j] -= carry_y ? yrs : 0;
+      cx[j] += sxs + (carry_y ? P.sin : 0);
+      aoff[j] += o_step + (carry_z ? o_cz : 0) + (carry_y ? o_cy : 0);
+      wg_raw_buffer_load_lds(rsA, (wg_lds_u32_ptr)(a + j * (ARS * PA)), 16, vo, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) wg_raw_buffer_load_lds(rsD, (wg_lds_u32_ptr)(d + j * 4096), 16, doffb + j * d_jstep, 0, 0, 0);
+    doffb += d_step;
   };
   auto sstore = [&](int buf) {
     char* a = smem + buf * CF::STAGE;
@@ -233,14 +306,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs P) {
     for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nst > 0) {
-    if constexpr (GLDS) gload_lds(0, 0);
+    if constexpr (GLDS) { if (use_buf) gload_lds_buf(0, 0); else gload_lds(0, 0); }
     else { gload(0); sstore(0); }
   }
   __syncthreads();
   for (int s = 0; s < nst; ++s) {
     const int buf = s & 1;
     if (s + 1 < nst) {
-      if constexpr (GLDS) gload_lds(s + 1, buf ^ 1);     // streams into the other buffer while this one feeds the MFMAs
+      if constexpr (GLDS) { if (use_buf) gload_lds_buf(s + 1, buf ^ 1); else gload_lds(s + 1, buf ^ 1); }   // streams into the other buffer while this one feeds the MFMAs
       else gload(s + 1);
     }
     const char* a = smem + buf * CF::STAGE;
@@ -399,6 +472,7 @@ template <typename T, bool SMALLC> static void launch_wgrad(WgradKArgs& a, hipSt
   static const bool remap = !(getenv("CTSEG_WGRAD_XCD") && atoi(getenv("CTSEG_WGRAD_XCD")) == 0);
   dim3 grid((unsigned)kb, (unsigned)cb, (unsigned)zs);
   a.kblocks = a.cblocks = 0;
+  a.addr64 = ((int64_t)a.Xi * a.Yi * a.Zi * a.g_ld * (int64_t)sizeof(T) >= ((int64_t)1 << 31) - 4096 || getenv("CTSEG_WGRAD_ADDR64") != nullptr) ? 1 : 0;
   if (remap && zs % 8 == 0 && kb * cb > 1) {
     a.kblocks = kb; a.cblocks = cb;
     grid = dim3((unsigned)(kb * cb * zs), 1u, 1u);
@@ -475,6 +549,7 @@ extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
   int rps = (int)((rows64 + d->splits - 1) / d->splits);
   rps = ((rps + 31) / 32) * 32;
   a.rows_per_split = rps;
+  CTSEG_REQUIRE((int64_t)(rps + 64) * d->d_ld * SZ < ((int64_t)1 << 31), "conv_wgrad: rows per split * row bytes exceed 32-bit offsets (raise splits)");
   a.kpad_w = d->kpad_w; a.cn_pad = d->cn_pad;
   int dv = ((d->Cn + EPC - 1) / EPC) * EPC;
   a.d_valid = dv < d->d_ld ? dv : d->d_ld;
