@@ -419,7 +419,10 @@ class GemmLayer:
         bnw = lib.ctseg_wgrad_tile_cols(cn)
         kpad_w, cn_pad = rup(self.T * cg + 1, 128), rup(cn, bnw)
         nwg = (kpad_w // 128) * (cn_pad // bnw) * N
-        splits = max(1, min(math.ceil(int(os.environ.get("CTSEG_WGRAD_TARGET_WGS", "2048")) / nwg), math.ceil(rows / 512), 1024))
+        # workgroups to aim for: 1024 with 16-bit storage (2048 measured +0.1 ms/step once the kernel's address code got cheaper:
+        # more slabs to write and reduce; 512 is +0.35); fp32 storage keeps 2048 (its trajectory test pins a summation order)
+        target = int(os.environ.get("CTSEG_WGRAD_TARGET_WGS", "1024" if nat.is16(plan.dt) else "2048"))
+        splits = max(1, min(math.ceil(target / nwg), math.ceil(rows / 512), 1024))
         # slabs (N * splits) in multiples of 8: the kernel then keeps all K / column blocks of a slab on one XCD (one L2 fetch
         # of the rows they share instead of one per XCD)
         m = 8 // math.gcd(N, 8)
