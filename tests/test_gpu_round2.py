@@ -647,3 +647,58 @@ def test_stride2_conv_32_to_128_with_register_resident_weights(monkeypatch, shap
     monkeypatch.setenv("CTSEG_NO_DOWN_R", "1")
     yg, _, _, _ = run_conv_module(mod, x, gy, BF16, DEV)
     assert rel_err(yy, yg) < 1e-2          # both round fp32 sums of the same products to bf16
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Generic weight gradient: multiply-free 32-bit gather addressing + range-checked buffer loads vs the 64-bit address chain
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,cin,cout,shape", [("conv", 64, 64, (2, 16, 16, 12)), ("conv", 128, 256, (1, 9, 7, 5)),
+                                                 ("conv_s2", 32, 128, (2, 18, 22, 10)), ("conv_s2", 64, 256, (1, 12, 14, 10)),
+                                                 ("convT", 128, 32, (1, 5, 9, 7)), ("conv", 256, 256, (3, 4, 6, 5))])
+def test_generic_weight_gradient_offset_addressing_equals_the_64_bit_chain(monkeypatch, kind, cin, cout, shape):
+    """conv_wgrad_kernel's bf16 loader keeps scaled row coordinates and a 32-bit byte offset per chunk, advanced by per-stage constants
+    with two carry corrections, and loads through range-checked buffer loads (voxels outside the volume, rows past the split and
+    columns past d_valid are out-of-range offsets).  CTSEG_WGRAD_ADDR64=1 selects the 64-bit chain samples >= 2 GiB use: the same
+    rows meet the same MFMAs in the same order, so weight and bias gradients must be BIT-identical (weight gradient of
+    torch.nn.Conv3d / ConvTranspose3d as in the reference's loss.backward(), capstone/volumetric/base_trainer.py:80-82).
+    Odd extents (carries on every axis inside a 32-row stage), several samples, stride 2, the transposed conv's swapped roles."""
+    from capstone_amd._native import BF16
+    from helpers import run_conv_module, rel_err
+    torch.manual_seed(cin + cout + shape[2])
+    if kind == "convT":
+        mod = torch.nn.ConvTranspose3d(cin, cout, 3, 2, 1, output_padding=1)
+    else:
+        mod = torch.nn.Conv3d(cin, cout, 3, 2 if kind == "conv_s2" else 1, 1)
+    x = torch.randn(shape[0], cin, *shape[1:])
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    _, _, gw, gb = run_conv_module(mod, x, gy, BF16, DEV)
+    assert rel_err(gw, mod.weight.grad) < 2.5e-2
+    assert rel_err(gb, mod.bias.grad) < 2.5e-2
+    monkeypatch.setenv("CTSEG_WGRAD_ADDR64", "1")
+    _, _, gw64, gb64 = run_conv_module(mod, x, gy, BF16, DEV)
+    assert np.array_equal(np.asarray(gw), np.asarray(gw64))
+    assert np.array_equal(np.asarray(gb), np.asarray(gb64))
+
+
+@pytest.mark.parametrize("kind,cin,cout,shape", [("convT", 384, 64, (1, 5, 6, 4)), ("conv_s2", 64, 256, (2, 12, 14, 10))])
+def test_parity_classes_longest_first_equals_index_order(monkeypatch, kind, cin, cout, shape):
+    """the generic 8-class passes (ConvTranspose3d 384 -> 64 forward; input gradient of the stride-2 Conv3d 64 -> 256) launch their
+    classes longest K loop first; a class's tiles are independent of the launch order, so outputs are bit-identical to index order
+    (CTSEG_CLASS_ORDER_KEEP=1)"""
+    from capstone_amd._native import BF16
+    from helpers import run_conv_module
+    torch.manual_seed(cin + shape[1])
+    if kind == "convT":
+        mod = torch.nn.ConvTranspose3d(cin, cout, 3, 2, 1, output_padding=1)
+    else:
+        mod = torch.nn.Conv3d(cin, cout, 3, 2, 1)
+    x = torch.randn(shape[0], cin, *shape[1:])
+    gy = torch.randn_like(mod(x))
+    y1, gx1, _, _ = run_conv_module(mod, x, gy, BF16, DEV)
+    monkeypatch.setenv("CTSEG_CLASS_ORDER_KEEP", "1")
+    y0, gx0, _, _ = run_conv_module(mod, x, gy, BF16, DEV)
+    assert np.array_equal(np.asarray(y1), np.asarray(y0))
+    assert np.array_equal(np.asarray(gx1), np.asarray(gx0))
