@@ -289,7 +289,11 @@ struct StemWgradArgs {
 
 template <int CT>
 __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArgs P, int total_tiles) {
-  constexpr int DBYTES = CT * 256 * 32, DCH = 256 * CT * 2, JD = DCH / 256;   // dy tile: planes of 16 channels, 32 B per voxel
+  // dy tile: planes of 16 channels, 32 B per voxel.  The plane pitch is 8 KiB + 32 B: the 8 lanes that store one voxel's 8 chunks
+  // (4 planes x 32 B) then cover 128 distinct bytes of the bank period; with a pitch of exactly 8 KiB the four planes fell on the
+  // same banks and every staging store was a 4-way conflict (768 conflict cycles per tile = 52 % of the kernel's LDS cycles)
+  constexpr int DPL = 256 * 32 + 32;
+  constexpr int DBYTES = CT * DPL, DCH = 256 * CT * 2, JD = DCH / 256;
   constexpr int BUF = S_INB + DBYTES;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   typedef s16x4 __attribute__((address_space(3)))* lds_s16x4;
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArg
     const int tx = tv >> 6, ty = (tv >> 3) & 7, tz = tv & 7;
     gd_byte[j] = ((tx * YZ + ty * P.Zr + tz) * P.d_ld + c * 8) * 2;
     gd_xyz[j] = tx | (ty << 8) | (tz << 16);
-    gd_lds[j] = (c >> 1) * (256 * 32) + tv * 32 + (c & 1) * 16;
+    gd_lds[j] = (c >> 1) * DPL + tv * 32 + (c & 1) * 16;
   }
   auto origin = [&](int t, int& n, int& x0, int& y0, int& z0) {
     n = t / P.G.tiles;
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArg
       bf16x8 df[CT];
 #pragma unroll
       for (int b = 0; b < CT; ++b) {
-        const char* p0 = ds + b * (256 * 32) + (((x * 8) + (yb + ly)) * 8 + lz0 + tq) * 32 + tp * 8;
+        const char* p0 = ds + b * DPL + (((x * 8) + (yb + ly)) * 8 + lz0 + tq) * 32 + tp * 8;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 2 * 8 * 32));
         const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};

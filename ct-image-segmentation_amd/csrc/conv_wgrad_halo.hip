@@ -42,7 +42,10 @@ template <int VB, int DBY, int NW>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_halo_kernel(const WgradHaloArgs P, int total_tiles) {
   constexpr int NTH = 64 * NW, TPW = (28 + NW - 1) / NW, TFULL = 27 / NW;    // taps per wave; taps every wave owns (the last may not exist)
   constexpr int PA = VB / 32, PB = DBY / 32;
-  constexpr int XBYTES = PA * WH_HV * 32, DBYTES = PB * WH_TV * 32, BUF = XBYTES + DBYTES;
+  // plane pitches padded by 64 B: with two planes the 8 lanes of a 16-byte staging store hold 2 voxels x 2 planes, and pitches
+  // that are multiples of the 256-byte bank period (19 200 / 8 192 B) put both planes of a voxel on the same banks
+  constexpr int XPL = WH_HV * 32 + (PA > 1 ? 64 : 0), DPL = WH_TV * 32 + (PB > 1 ? 64 : 0);
+  constexpr int XBYTES = PA * XPL, DBYTES = PB * DPL, BUF = XBYTES + DBYTES;
   constexpr int XCH = WH_HV * (VB / 16), DCH = WH_TV * (DBY / 16);
   constexpr int JX = (XCH + NTH - 1) / NTH, JD = (DCH + NTH - 1) / NTH;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_halo_kernel(const WgradHal
     const int hx = hv / 100, rem = hv - hx * 100, hy = rem / 10, hz = rem - hy * 10;
     gx_byte[j] = (((hx - 1) * YZ + (hy - 1) * P.Z + (hz - 1)) * P.g_ld + c * 8) * 2;
     gx_hxyz[j] = (idx < XCH) ? (hx | (hy << 8) | (hz << 16)) : 0x7f7f7f;
-    gx_lds[j] = (c >> 1) * (WH_HV * 32) + hv * 32 + (c & 1) * 16;
+    gx_lds[j] = (c >> 1) * XPL + hv * 32 + (c & 1) * 16;
   }
 #pragma unroll
   for (int j = 0; j < JD; ++j) {
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_halo_kernel(const WgradHal
     const int tx = tv >> 6, ty = (tv >> 3) & 7, tz = tv & 7;
     gd_byte[j] = ((tx * YZ + ty * P.Z + tz) * P.d_ld + c * 8) * 2;
     gd_xyz[j] = (idx < DCH) ? (tx | (ty << 8) | (tz << 16)) : 0x7f7f7f;
-    gd_lds[j] = (c >> 1) * (WH_TV * 32) + tv * 32 + (c & 1) * 16;
+    gd_lds[j] = (c >> 1) * DPL + tv * 32 + (c & 1) * 16;
   }
   u32x4 rx[JX], rd[JD];
   // 12-wide bf16 rows (24 bytes): chunk 1 is channels 8..11 + zero fill (32-byte planes only)
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_halo_kernel(const WgradHal
       bf16x8 df[PB];
 #pragma unroll
       for (int b = 0; b < PB; ++b) {
-        const char* p0 = ds + b * (WH_TV * 32) + (((x * 8) + (yb + ly)) * 8 + lz) * 32 + tp * 8;
+        const char* p0 = ds + b * DPL + (((x * 8) + (yb + ly)) * 8 + lz) * 32 + tp * 8;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 2 * 8 * 32));
         const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_halo_kernel(const WgradHal
         const int h = hbase + P.delta[wave + NW * ti];
 #pragma unroll
         for (int a = 0; a < PA; ++a) {
-          const char* p0 = xs + a * (WH_HV * 32) + h * 32 + tp * 8;
+          const char* p0 = xs + a * XPL + h * 32 + tp * 8;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 2 * 10 * 32));
           const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_halo_kernel(const WgradHal
           const int h = hbase + P.delta[tap];
 #pragma unroll
           for (int a = 0; a < PA; ++a) {
-            const char* p0 = xs + a * (WH_HV * 32) + h * 32 + tp * 8;
+            const char* p0 = xs + a * XPL + h * 32 + tp * 8;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 2 * 10 * 32));
             const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
