@@ -21,7 +21,7 @@
 #include "conv_common.h"
 
 #ifndef X_ABL
-#define X_ABL 0      // timing-only ablation builds (tools/ablate_halo_x.sh): 1 = no MFMAs, 2 = no stores, 4 = no DMA; results are garbage
+#define X_ABL 0      // timing-only ablation builds (tools/ablate_halo_x.sh): 1 = no MFMAs, 2 = no stores, 4 = no DMA, 128 = no 8-byte staging stores (12-wide rows); results are garbage
 #endif
 
 namespace ctseg {
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     if (!nrm) {
 #pragma unroll
       for (int j = 0; j < R_J; ++j)
-        if (R_J * NTHR == R_N || tid + j * NTHR < R_N) *reinterpret_cast<u32x2*>(dst + rlds[j]) = rg[j];
+        if ((R_J * NTHR == R_N || tid + j * NTHR < R_N) && (!(X_ABL & 128) || rg[j][0] == 0x12345678u)) *reinterpret_cast<u32x2*>(dst + rlds[j]) = rg[j];
       return;
     }
     const uint32_t notm = ~(range_mask(1 - o.x0, P.Xi - o.x0, X_HX) | (range_mask(1 - o.y0, P.Yi - o.y0, X_HY) << 6) |
