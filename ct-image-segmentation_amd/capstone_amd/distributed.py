@@ -71,10 +71,33 @@ class GradAllReducer:
         self.active = self.world > 1 or (always and dist.is_initialized())
         self.points = split_points(ready_marks, sizes, n) if ready_marks else []
         self.works, self.sent = [], 0
+        self.algo = os.environ.get("CTSEG_DDP_ALGO", "allreduce")      # "direct": all-to-all + local sum + all-gather
+        self._keep = []
 
     def _launch(self, lo, hi):
-        if hi > lo and self.active:
+        if hi <= lo or not self.active:
+            return
+        if self.algo == "direct" and self.world > 1 and hi - lo >= self.world:
+            self._launch_direct(lo, hi)
+        else:
             self.works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _launch_direct(self, lo, hi):
+        """CTSEG_DDP_ALGO=direct — the exchange SURVEY.md §5 prefers on a fully connected xGMI node, two hops instead of a ring's
+        2 (W - 1): every rank sends shard k of the chunk straight to rank k (all-to-all = point-to-point copies over the direct
+        links), sums the W copies of its own shard in rank order (deterministic), and the reduced shards travel back the same
+        way (all-gather).  Issued from the stream the hook runs on; the tail that does not divide by W is all-reduced.
+        Not the default: unmeasured on an 8-GPU node."""
+        W = self.world
+        shard = (hi - lo) // W
+        body = self.flat_g[lo:lo + W * shard]
+        recv = torch.empty_like(body)
+        dist.all_to_all_single(recv, body, group=self.group)              # recv[k] = rank k's copy of MY shard
+        mine = recv.view(W, shard).sum(dim=0)
+        self.works.append(dist.all_gather_into_tensor(body, mine, group=self.group, async_op=True))
+        if lo + W * shard < hi:
+            self.works.append(dist.all_reduce(self.flat_g[lo + W * shard:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._keep.append((recv, mine))       # alive until finish(): the collectives read them asynchronously
 
     def points_for(self, plan):
         """split points of THIS plan's backward program (another batch shape, or the 16-wide fallback of the narrow-row layout,
@@ -88,7 +111,7 @@ class GradAllReducer:
 
     def hooks(self, plan=None):
         """{backward program index: callable} — fired by Plan.backward between ops"""
-        self.works, self.sent = [], 0
+        self.works, self.sent, self._keep = [], 0, []
         h = {}
         for idx, end in self.points_for(plan):
             def fire(end=end):
@@ -104,6 +127,7 @@ class GradAllReducer:
         for w in self.works:
             w.wait()
         self.works = []
+        self._keep = []
         return 1.0 / self.world
 
 

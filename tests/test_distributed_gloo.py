@@ -63,6 +63,50 @@ def test_flat_gradient_allreduce_world2():
         np.testing.assert_array_equal(p, np.zeros(1000, dtype=np.float32))  # rank 0's parameters everywhere
 
 
+def _worker_direct(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      CTSEG_DDP_ALGO="direct")
+    cdist.init_from_env("gloo")
+    n = 1003                                                              # chunks that do not divide by the world size
+    sizes = {0: 101, 101: 400, 501: 300, 801: 202}
+    marks = [(3, [0]), (7, [101, 501]), (12, [801])]
+    g = torch.Generator().manual_seed(100 + rank)
+    flat_g = torch.randn(n, generator=g)
+    mine = flat_g.clone()
+    red = cdist.GradAllReducer(flat_g, n, marks, sizes)
+    assert red.algo == "direct"
+    hooks = red.hooks()
+    for idx in range(15):
+        if idx in hooks:
+            hooks[idx]()
+    red.finish()
+    q.put((rank, mine.numpy(), flat_g.clone().numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_direct_exchange_equals_the_sum_over_ranks(world):
+    """CTSEG_DDP_ALGO=direct: all-to-all of the shards, local sum in rank order, all-gather — every rank must end with the same
+    buffer, equal to the rank-ordered sum (the mean is the Adam kernel's grad_scale; Lightning DDP's gradient mean,
+    capstone/volumetric/base_trainer.py:196,217).  Chunk lengths that do not divide by the world size exercise the all-reduced tail."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_direct, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    exp = res[0][1].copy()
+    for _, mine, _ in res[1:]:
+        exp = exp + mine                                                   # rank order, fp32
+    for _, _, got in res:
+        np.testing.assert_array_equal(got, res[0][2])                      # identical on every rank
+        np.testing.assert_allclose(got, exp, rtol=0, atol=1e-6)
+
+
 def test_split_points_follow_readiness_prefix():
     sizes = {0: 10, 10: 10, 20: 60, 80: 20}
     # offset 20 (the big bottleneck tensor) becomes final before offset 10: the prefix only advances when contiguous
