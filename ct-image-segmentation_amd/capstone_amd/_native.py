@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libctseg_hip.so")
 
 F32, BF16, I16, U8, F16 = 0, 1, 2, 3, 4      # F16: IEEE half storage, forward (inference) passes only
 MAX_TAPS, MAX_CLASSES = 27, 8
+ABI_VERSION = 2              # CTSEG_ABI_VERSION of include/ctseg_hip.h this binding mirrors
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 _EPC = {F32: 4, BF16: 8, F16: 8}
 _SZ = {F32: 4, BF16: 2, F16: 2}
@@ -47,8 +48,16 @@ class ConvClass(C.Structure):
                 ("ox", C.c_int32), ("oy", C.c_int32), ("oz", C.c_int32), ("taps", C.c_int32 * MAX_TAPS)]
 
 
-class ConvDesc(C.Structure):
-    _fields_ = [("in_", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+class _SizedDesc(C.Structure):
+    """ABI 2: a descriptor starts with the size of the struct its caller was compiled against (checked by every entry point)"""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(self)
+
+
+class ConvDesc(_SizedDesc):
+    _fields_ = [("struct_size", C.c_int32), ("reserved0", C.c_int32), ("in_", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
                 ("add", C.c_void_p), ("stats", C.c_void_p), ("dtype", C.c_int32),
                 ("N", C.c_int32), ("Xi", C.c_int32), ("Yi", C.c_int32), ("Zi", C.c_int32),
                 ("Xr", C.c_int32), ("Yr", C.c_int32), ("Zr", C.c_int32),
@@ -62,8 +71,8 @@ class ConvDesc(C.Structure):
                 ("in_mean_rstd", C.c_void_p), ("in_alpha", C.c_void_p), ("in_norm_C", C.c_int32)]
 
 
-class WgradDesc(C.Structure):
-    _fields_ = [("in_", C.c_void_p), ("dy", C.c_void_p), ("ws", C.c_void_p), ("dtype", C.c_int32),
+class WgradDesc(_SizedDesc):
+    _fields_ = [("struct_size", C.c_int32), ("reserved0", C.c_int32), ("in_", C.c_void_p), ("dy", C.c_void_p), ("ws", C.c_void_p), ("dtype", C.c_int32),
                 ("N", C.c_int32), ("Xi", C.c_int32), ("Yi", C.c_int32), ("Zi", C.c_int32),
                 ("Xr", C.c_int32), ("Yr", C.c_int32), ("Zr", C.c_int32),
                 ("Cg", C.c_int32), ("Cn", C.c_int32), ("g_ld", C.c_int32), ("d_ld", C.c_int32), ("sin", C.c_int32),
@@ -132,8 +141,9 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.ctseg_abi_version() != 1:
-            raise NativeError("libctseg_hip.so ABI version mismatch")
+        if L.ctseg_abi_version() != ABI_VERSION:
+            raise NativeError(f"libctseg_hip.so reports ABI version {L.ctseg_abi_version()}, this binding is written against "
+                              f"{ABI_VERSION} (include/ctseg_hip.h): rebuild with `make -C ct-image-segmentation_amd`")
         _lib = L
     return _lib
 

@@ -77,6 +77,58 @@ class _SegLossFn(torch.autograd.Function):
         return g, None, None, None, None, None
 
 
+class _SegLossTableFn(torch.autograd.Function):
+    """the unreduced (B, C-1) / (B, C) table of ONE loss (``reduction="none"``); backward takes the table's gradient"""
+
+    @staticmethod
+    def forward(ctx, logits, eng, plan, name):
+        ptr, ld, keep = _as_cl(logits)
+        eng.stats(ptr, ld)
+        ctx.eng, ctx.plan, ctx.name, ctx.cl, ctx.shape = eng, plan, name, (ptr, ld, keep), logits.shape
+        return eng.loss_table(name)
+
+    @staticmethod
+    def backward(ctx, g):
+        eng = ctx.eng
+        ptr, ld, _ = ctx.cl
+        eng.stats(ptr, ld)              # another entry's forward may have run on the same engine since
+        eng.build_coef({ctx.name: g})
+        B, C = ctx.shape[:2]
+        ldn = (C + 3) // 4 * 4
+        buf = torch.zeros((B, eng.S, ldn), dtype=torch.float32, device=eng.device)
+        eng.grad(ptr, ld, buf.data_ptr(), ldn, nat.F32)
+        return buf[..., :C].permute(0, 2, 1).reshape(ctx.shape), None, None, None
+
+
+class LossEntry(nn.Module):
+    """One value of ``MultipleLossWrapper.losses`` — the reference builds ``nn.ModuleDict({name: LOSSES[name](reduction=...)})``
+    (capstone/models/losses.py:177-180) and code that iterates ``loss_func.losses.items()`` calls ``fx(input, target)``.
+    Same call, same return: a scalar for ``reduction="mean"`` and for the two cross-entropies (whose wrappers ignore the
+    argument, :45-68), the (B, C-1) Dice / GeneralizedDice or (B, C) Focal table for ``reduction="none"`` — computed by the
+    fused HIP loss pass, differentiable w.r.t. ``input``."""
+
+    def __init__(self, name, reduction="mean"):
+        super().__init__()
+        self.name, self.reduction = name, reduction
+        if name == "WeightedCrossEntropy":
+            self.weight = torch.as_tensor(list(WEIGHT.values()))     # attribute the reference's wrapper carries (:64)
+
+    def forward(self, input, target):
+        nat.require_gpu(input, f"{self.name} loss")
+        eng, plan = _engine_for(input)
+        stash = getattr(target, "_ctseg_labels", None)
+        if stash is not None:
+            eng.set_labels(*stash)
+        else:
+            eng.set_labels_from_i64(target)
+        if self.reduction == "none" and self.name not in ("CrossEntropy", "WeightedCrossEntropy"):
+            return _SegLossTableFn.apply(input, eng, None, self.name)
+        return _SegLossFn.apply(input, eng, None, (self.name,), False, None)[0]
+
+    def extra_repr(self):
+        return f"{self.name}, reduction={self.reduction!r}"
+
+
 class MultipleLossWrapper(nn.Module):
     def __init__(self, losses, exclude_missing=False):
         super().__init__()
@@ -86,6 +138,11 @@ class MultipleLossWrapper(nn.Module):
                 raise NotImplementedError("Boundary loss needs CPU distance maps (2-D pipeline); outside the MI355X hot path")
             assert name in LOSSES.keys()
         self.names = list(losses)
+        # the reference's attribute (models/losses.py:177-180): one module per requested loss, keyed by name, built with
+        # reduction "none" under exclude_missing.  forward() below computes all of them in ONE pass over the logits instead of
+        # calling the entries one by one; each entry is callable on its own with the reference's (input, target) signature.
+        reduction = "none" if exclude_missing else "mean"
+        self.losses = nn.ModuleDict({name: LossEntry(name, reduction) for name in losses})
 
     def forward(self, input, target, mask_indicator=None, dist_maps=None):
         nat.require_gpu(input, "MultipleLossWrapper")

@@ -346,33 +346,27 @@ def _make_side_stream(device):
     (hipStreamCreateWithPriority through the runtime library torch already loaded), wrapped for torch; default: a plain stream."""
     want = os.environ.get("CTSEG_SIDE_PRIORITY", "")
     if want in ("low", "high"):
-        import ctypes
-        try:
-            hip = ctypes.CDLL("libamdhip64.so")
-            least, greatest = ctypes.c_int(0), ctypes.c_int(0)
-            if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0:
-                h = ctypes.c_void_p()
-                prio = least.value if want == "low" else greatest.value
-                with torch.cuda.device(device):
-                    rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(prio))   # 1 = hipStreamNonBlocking
-                if rc == 0 and h.value:
-                    if os.environ.get("CTSEG_SIDE_PRIORITY_VERBOSE"):
-                        print(f"side stream priority {prio} (range {least.value}..{greatest.value})", file=sys.stderr)
-                    return torch.cuda.ExternalStream(h.value, device=device)
-        except OSError:
-            pass
+        # created by torch itself, i.e. in the HIP runtime torch has loaded (a second libamdhip64 bound by soname could be the
+        # system's copy beside the wheel's: a stream handle of one runtime is invalid in the other).  torch: lower number = higher
+        # priority; 0 is the default, negative values are clamped to the device's greatest priority.
+        prio = 0 if want == "low" else -1
+        if os.environ.get("CTSEG_SIDE_PRIORITY_VERBOSE"):
+            print(f"side stream priority {prio} (torch convention: -1 = high, 0 = default / lowest)", file=sys.stderr)
+        return torch.cuda.Stream(device=device, priority=prio)
     return torch.cuda.Stream(device=device)
 
 
 class Plan:
-    def __init__(self, engine, N, X, Y, Z, inference=False, need_input_grad=False):
+    def __init__(self, engine, N, X, Y, Z, inference=False, need_input_grad=False, dt=None):
         net = engine.net
         self.inference = inference        # forward program only: no gradient buffers, no backward program
-        self.engine, self.store, self.dt, self.device = engine, engine.store, engine.dt, engine.device
+        self.engine, self.store, self.device = engine, engine.store, engine.device
+        self.dt = engine.dt if dt is None else dt        # storage dtype of THIS plan (Engine.train_dt() for training plans)
         if self.dt == nat.F16 and not inference:
             # the weight-gradient / norm-backward / loss-gradient kernels exist for bf16 and fp32 storage only: without loss scaling
             # the gradients of this step underflow in half precision anyway (d loss / d logit ~ 1 / (B * voxels) = 4e-8 at
-            # 2 x 512 x 512 x 48, below the smallest half subnormal 6e-8); bf16 has fp32's range at the same MFMA rate
+            # 2 x 512 x 512 x 48, below the smallest half subnormal 6e-8); bf16 has fp32's range at the same MFMA rate.
+            # (Engine.plan_for_shape never asks for this: it records the training plans of an fp16 model in bf16, with a warning.)
             raise nat.NativeError("precision='fp16' (IEEE half storage) is implemented for inference: run under torch.no_grad() / "
                                   "the sliding-window inferer, and train with precision='bf16' or 'fp32'")
         self.dims = net.dimensions
@@ -594,6 +588,22 @@ class Engine:
         self.device = None
         self.plans = {}
         self.last_plan = None
+        self._warned_fp16_train = False
+
+    def train_dt(self):
+        """storage dtype of the TRAINING plans.  A model built with Lightning's ``--precision 16`` (IEEE half) runs its inference
+        plans in fp16 and trains in bf16 storage — the reference's stack trains under that flag with native AMP + loss scaling
+        (capstone/volumetric/base_trainer.py:217 exposes it); here there is no loss scaling and no fp16 backward kernel family,
+        and bf16 has fp32's exponent range at the same MFMA rate.  Said once, loudly; never silent."""
+        if self.dt != nat.F16:
+            return self.dt
+        if not self._warned_fp16_train:
+            import warnings
+            warnings.warn("precision=16 (IEEE half): training plans run in bf16 storage / fp32 accumulation (no loss scaling is "
+                          "needed); validation, test and sliding-window inference run in fp16 storage as asked. Pass "
+                          "precision='bf16' to use one storage dtype throughout.", RuntimeWarning, stacklevel=3)
+            self._warned_fp16_train = True
+        return BF16
 
     def _param_order(self):
         """backward (gradient-readiness) order: up path of the top level first, stem last"""
@@ -616,9 +626,18 @@ class Engine:
     def ensure(self, device):
         device = torch.device(device)
         if self.store is None or self.device != device:
+            old = self.store
             self.device = device
             self.store = ParamStore(self._param_order(), device)
             self.plans = {}
+            if old is not None and old.step > 0 and old.adam_m is not None and old.n == self.store.n:
+                # the module changed device with optimizer state in the old store (a checkpoint loaded on the CPU, then .to(cuda);
+                # Lightning calls on_load_checkpoint before it moves the module): Adam's moments and step count move with it.
+                # The parameter VALUES come from the Parameters themselves (ParamStore.__init__), which .to() has moved.
+                self.store.ensure_adam_state()
+                self.store.adam_m.copy_(old.adam_m.to(device))
+                self.store.adam_v.copy_(old.adam_v.to(device))
+                self.store.step = old.step
         elif not self.store.attached():
             # someone replaced parameter storage (load_state_dict keeps views; .to()/.float() does not)
             with torch.no_grad():
@@ -645,31 +664,35 @@ class Engine:
             if v % (2 ** nlev):
                 raise ValueError(f"spatial size {v} is not divisible by 2^{nlev} (the skip concat needs it, as in MONAI)")
         key = (N,) + sp
+        tdt = self.dt if inference else self.train_dt()
+        if tdt != self.dt:
+            key = key + ("train-bf16",)     # an fp16 model's training plans (bf16 storage) are never reused for its fp16 inference
         if need_input_grad and not inference:
             plan = self.plans.get(key + ("dx",))
             if plan is None:
-                plan = self.plans[key + ("dx",)] = self._record(N, sp, False, True)
+                plan = self.plans[key + ("dx",)] = self._record(N, sp, False, True, tdt)
             self.last_plan = plan
             return plan
         plan = self.plans.get(key) or self.plans.get(key + ("dx",)) or (self.plans.get(key + ("inference",)) if inference else None)
         if plan is None:
-            plan = self.plans[key + (("inference",) if inference else ())] = self._record(N, sp, inference)
+            plan = self.plans[key + (("inference",) if inference else ())] = self._record(N, sp, inference, False, tdt)
         self.last_plan = plan
         return plan
 
-    def _record(self, N, sp, inference, need_input_grad=False):
+    def _record(self, N, sp, inference, need_input_grad=False, dt=None):
         """record a Plan; bf16 tensors of 9..12 channels (the class logits' neighbours) are laid out 12 wide when every pass
         that touches them can move such rows (ctseg_conv_narrow_ok / ctseg_wgrad_narrow_ok), 16 wide otherwise"""
         from . import engine as eng
-        if nat.is16(self.dt) and os.environ.get("CTSEG_NARROW_ROWS", "1") != "0":
+        dt = self.dt if dt is None else dt
+        if nat.is16(dt) and os.environ.get("CTSEG_NARROW_ROWS", "1") != "0":
             eng.NARROW_ROWS[0] = True
             try:
-                return Plan(self, N, *sp, inference=inference, need_input_grad=need_input_grad)
+                return Plan(self, N, *sp, inference=inference, need_input_grad=need_input_grad, dt=dt)
             except eng.NarrowUnsupported:
                 pass
             finally:
                 eng.NARROW_ROWS[0] = False
-        return Plan(self, N, *sp, inference=inference, need_input_grad=need_input_grad)
+        return Plan(self, N, *sp, inference=inference, need_input_grad=need_input_grad, dt=dt)
 
     # ---- raw (no autograd) API used by the native training step, bench and tests ----
     def forward(self, x):
@@ -677,6 +700,11 @@ class Engine:
 
     def logits_view(self, plan=None):
         plan = plan or self.last_plan
+        if not getattr(plan, "logits_current", True):
+            # the last forward on this plan stopped before the logits convolution (fit_step(keep_logits=False): the cross-entropy
+            # ran in that convolution's epilogue and the fp32 logits were never written): what the buffer holds is an older step's
+            raise nat.NativeError("the logits of the last step were not materialised (fit_step(keep_logits=False) fuses the "
+                                  "cross-entropy into the logits convolution); run the step with keep_logits=True, or a forward")
         v = plan.logits.valid()
         return v[..., 0] if self.net.dimensions == 2 else v
 

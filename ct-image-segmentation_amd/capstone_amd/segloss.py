@@ -185,6 +185,30 @@ class SegLossEngine:
                 raise KeyError(name)
         return out
 
+    def loss_table(self, name):
+        """the unreduced per-(sample, class) table of one loss after ``stats()`` — what the reference's wrapper returns with
+        ``reduction="none"`` (capstone/models/losses.py:177-180 builds every entry that way under ``exclude_missing``):
+        Dice / GeneralizedDice (B, C-1) (background excluded), Focal (B, C)"""
+        P, I, FO, Y = self._tables()
+        if name == "Dice":
+            return (1.0 - (2.0 * I + SMOOTH) / (P + Y + SMOOTH))[:, 1:].float()
+        if name == "GeneralizedDice":
+            w = self._gdl_w(Y)
+            return (1.0 - (2.0 * I * w + SMOOTH) / ((P + Y) * w + SMOOTH))[:, 1:].float()
+        if name == "Focal":
+            return (FO / self.S).float()
+        raise KeyError(name)
+
+    def _table_weight(self, name, g):
+        """weight of table entry (b, c) in the scalar being differentiated: ``_w[name] * g`` for the reduced losses, or the
+        upstream gradient itself when the caller took the unreduced table (``g`` is then (B, C-1) or (B, C))"""
+        g = torch.as_tensor(g, dtype=torch.float64, device=self.device)
+        if g.ndim == 2:
+            if g.shape[1] == self.C - 1:
+                g = torch.cat([torch.zeros_like(g[:, :1]), g], 1)
+            return g
+        return self._w[name].double() * g
+
     def _gdl_w(self, Y):
         y = Y.float()
         w = torch.reciprocal(y * y)                      # models/temp.py:90-94 (Weight.SQUARE)
@@ -218,24 +242,24 @@ class SegLossEngine:
         fcoef = torch.zeros((B, C), dtype=torch.float64, device=dev)
         cw = torch.zeros(C, dtype=torch.float64, device=dev)
         for name, g in scales.items():
-            g = torch.as_tensor(g, dtype=torch.float64, device=dev)
+            g = torch.as_tensor(g, dtype=torch.float64, device=dev)     # 0-dim, or the (B, C[-1]) gradient of an unreduced table
             if name == "CrossEntropy":
                 cw = cw + g / float(B * S)
             elif name == "WeightedCrossEntropy":
                 cw = cw + g * self.cw.double() / (self.hist.double() * self.cw.double()[None, :]).sum()
             elif name == "Dice":
                 D = P + Y + SMOOTH
-                wt = self._w[name].double() * g
+                wt = self._table_weight(name, g)
                 a = a - 2.0 * wt / D
                 b = b + wt * (2.0 * I + SMOOTH) / (D * D)
             elif name == "GeneralizedDice":
                 w = self._gdl_w(Y)
                 D = (P + Y) * w + SMOOTH
-                wt = self._w[name].double() * g
+                wt = self._table_weight(name, g)
                 a = a - 2.0 * w * wt / D
                 b = b + wt * w * (2.0 * I * w + SMOOTH) / (D * D)
             elif name == "Focal":
-                fcoef = fcoef + self._w[name].double() * g / float(S)
+                fcoef = fcoef + self._table_weight(name, g) / float(S)
         self.cw_eff.copy_(cw.float())
         self.coef[:, 0] = 1.0
         self.coef[:, 1:1 + C] = a.float()

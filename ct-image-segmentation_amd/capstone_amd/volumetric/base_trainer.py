@@ -93,9 +93,9 @@ SEED = 12342
 
 def _precision(kwargs):
     """Lightning's Trainer flag arrives through **vars(args) too.  ``--precision 16`` is IEEE half, as in the reference's stack
-    (Lightning 1.0 native AMP): here that is fp16 STORAGE for the inference passes (validation / test / sliding window); a
-    training step in it raises with the reason (no loss scaling; bf16 is the 16-bit training dtype).  Nothing is remapped
-    silently: "bf16" has to be asked for by name."""
+    (Lightning 1.0 native AMP): fp16 STORAGE for the inference passes (validation / test / sliding window), and bf16 storage
+    for the training plans after a one-time RuntimeWarning (plan.Engine.train_dt: no fp16 backward kernels, no loss scaling;
+    bf16 has fp32's range).  "bf16" by name uses bf16 throughout.  Nothing is remapped silently."""
     p = kwargs.get("precision", "fp32")
     if p in (16, "16", "fp16", "16-mixed", "16-true"):
         return "fp16"
@@ -172,7 +172,7 @@ class BaseUNet3D(_Base):
     # ---- native step: what Lightning's loop does per batch, without autograd -------------------------
     def fit_step(self, batch, betas=(0.9, 0.999), eps=1e-8, keep_logits=True):
         """keep_logits=False lets a cross-entropy-only step run the logits convolution with the loss fused into its epilogue
-        (ctseg_conv_logits_ce): the fp32 logits are then never materialised and ``engine.logits_view()`` is stale after the step;
+        (ctseg_conv_logits_ce): the fp32 logits are then never materialised and ``engine.logits_view()`` raises after the step;
         loss, Dice metric, gradients and the update are the same (gradient of the loss w.r.t. the logits bit-identical)."""
         images, masks, mask_indicator = batch
         nat.require_gpu(images, "fit_step")

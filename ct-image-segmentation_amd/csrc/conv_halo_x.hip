@@ -998,7 +998,7 @@ static void x_fill(const ctseg_conv_desc* d, ConvKArgs& a) {
 }
 
 extern "C" int ctseg_conv_logits_ce_slots(const ctseg_conv_desc* d, int32_t C) {
-  if (d == nullptr || d->nclass != 1) return 0;
+  if (!desc_ok(d) || d->nclass != 1) return 0;
   ConvKArgs a;
   x_fill(d, a);
   a.stats = nullptr;
@@ -1009,7 +1009,8 @@ extern "C" int ctseg_conv_logits_ce_slots(const ctseg_conv_desc* d, int32_t C) {
 extern "C" int ctseg_conv_logits_ce(const ctseg_conv_desc* d, const uint8_t* labels, int32_t C, const float* class_weight,
                                     const float* coef, int32_t coef_stride, void* dlogits, int32_t g_ld, double* part, int32_t P,
                                     int32_t R, int64_t* cnt, void* stream) {
-  CTSEG_REQUIRE(d && d->in && d->w && labels && coef && dlogits && part && cnt, "conv_logits_ce: null pointer");
+  CTSEG_REQUIRE_DESC(d, "conv_logits_ce");
+  CTSEG_REQUIRE(d->in && d->w && labels && coef && dlogits && part && cnt, "conv_logits_ce: null pointer");
   CTSEG_REQUIRE(d->nclass == 1, "conv_logits_ce: one tap class expected");
   ConvKArgs a;
   x_fill(d, a);

@@ -325,7 +325,8 @@ extern "C" int ctseg_conv_tile_rows(int32_t Cn) { return Cn <= 32 ? 256 : 128; }
 extern "C" int ctseg_conv_tile_cols(int32_t Cn) { return Cn <= 16 ? 16 : Cn <= 32 ? 32 : Cn <= 64 ? 64 : 128; }
 
 extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
-  CTSEG_REQUIRE(d != nullptr && d->in && d->w && d->out, "conv_igemm: null pointer");
+  CTSEG_REQUIRE_DESC(d, "conv_igemm");
+  CTSEG_REQUIRE(d->in && d->w && d->out, "conv_igemm: null pointer");
   CTSEG_REQUIRE(d->dtype == CTSEG_F32 || is16(d->dtype), "conv_igemm: bad dtype %d", d->dtype);
   const int SZ = d->dtype == CTSEG_F32 ? 4 : 2, EPC = 16 / SZ, BK = 128 / SZ;
   const int OSZ = d->out_f32 ? 4 : SZ, EPO = 16 / OSZ;
@@ -451,7 +452,7 @@ static void fill_args(const ctseg_conv_desc* d, ConvKArgs& a) {
 }
 
 extern "C" int ctseg_conv_split_ok(const ctseg_conv_desc* d) {
-  if (d == nullptr || d->nclass != 1 || d->add != nullptr) return 0;
+  if (!desc_ok(d) || d->nclass != 1 || d->add != nullptr) return 0;
   ConvKArgs a;
   fill_args(d, a);
   a.out_f32 = d->out_f32; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo; a.add = nullptr; a.o_ld = d->o_ld;
@@ -463,7 +464,7 @@ extern "C" int ctseg_conv_split_ok(const ctseg_conv_desc* d) {
 }
 
 extern "C" int ctseg_conv_in_norm_ok(const ctseg_conv_desc* d) {
-  if (d == nullptr || !is16(d->dtype) || d->nclass < 1) return 0;
+  if (!desc_ok(d) || !is16(d->dtype) || d->nclass < 1) return 0;
   ConvKArgs a;
   fill_args(d, a);
   return (conv_halo_eligible(a, d->dtype, d->nclass) && conv_halo_x_in_norm_ok(a, d->dtype, d->nclass)) ? 1 : 0;
@@ -473,7 +474,7 @@ extern "C" int ctseg_conv_in_norm_ok(const ctseg_conv_desc* d) {
 // the resident-weight LDS-halo kernel (any of them narrow), by the stride-2 "up" kernel (narrow output / addend only) or by the
 // stride-2 "down" halo kernel (narrow gathered operand only)
 extern "C" int ctseg_conv_narrow_ok(const ctseg_conv_desc* d) {
-  if (d == nullptr || !is16(d->dtype) || d->nclass < 1) return 0;
+  if (!desc_ok(d) || !is16(d->dtype) || d->nclass < 1) return 0;
   ConvKArgs a;
   fill_args(d, a);
   a.out_f32 = d->out_f32; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo; a.add = (const char*)d->add; a.o_ld = d->o_ld;
@@ -488,7 +489,7 @@ extern "C" int ctseg_conv_narrow_ok(const ctseg_conv_desc* d) {
 
 // tiles per sample (all classes) a pass with this geometry writes InstanceNorm partials for
 extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
-  if (d == nullptr || d->nclass < 1) return -1;
+  if (!desc_ok(d) || d->nclass < 1) return -1;
   ConvKArgs a;
   fill_args(d, a);
   if (conv_halo_eligible(a, d->dtype, d->nclass)) return conv_halo_slots(a, d->dtype);

@@ -491,23 +491,24 @@ extern "C" int ctseg_wgrad_tile_cols(int32_t Cn) { return Cn <= 16 ? 16 : Cn <= 
 
 // number of fp32 slabs [kpad_w][cn_pad] a ctseg_conv_wgrad call with this descriptor writes into `ws`
 extern "C" int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d) {
-  if (d == nullptr) return -1;
+  if (!desc_ok(d)) return -1;
   if (wgrad_halo_eligible(d)) return wgrad_halo_slabs(d);
   if (wgrad_up_eligible(d)) return wgrad_up_slabs(d);
   if (wgrad_stem_eligible(d)) return wgrad_stem_slabs(d);
   return d->N * d->splits;
 }
 
-extern "C" int ctseg_wgrad_in_norm_ok(const ctseg_wgrad_desc* d) { return (d != nullptr && d->dtype == CTSEG_BF16 && wgrad_halo_in_norm_ok(d)) ? 1 : 0; }
+extern "C" int ctseg_wgrad_in_norm_ok(const ctseg_wgrad_desc* d) { return (desc_ok(d) && d->dtype == CTSEG_BF16 && wgrad_halo_in_norm_ok(d)) ? 1 : 0; }
 
 extern "C" int ctseg_wgrad_narrow_ok(const ctseg_wgrad_desc* d) {
-  if (d == nullptr) return 0;
+  if (!desc_ok(d)) return 0;
   if (wgrad_halo_eligible(d)) return 1;
   return (d->d_ld != 12 && wgrad_up_eligible(d)) ? 1 : 0;      // the stride-2 transposed-conv kernel takes a 12-wide gathered operand
 }
 
 extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
-  CTSEG_REQUIRE(d != nullptr && d->in && d->dy && d->ws, "conv_wgrad: null pointer");
+  CTSEG_REQUIRE_DESC(d, "conv_wgrad");
+  CTSEG_REQUIRE(d->in && d->dy && d->ws, "conv_wgrad: null pointer");
   CTSEG_REQUIRE(d->dtype == CTSEG_F32 || d->dtype == CTSEG_BF16, "conv_wgrad: bad dtype");
   const int SZ = d->dtype == CTSEG_F32 ? 4 : 2, EPC = 16 / SZ;
   const bool halo = wgrad_halo_eligible(d);     // also moves 12-wide bf16 rows (ctseg_wgrad_narrow_ok)

@@ -155,6 +155,13 @@ void set_error(const char* fmt, ...);
     }                                                                    \
   } while (0)
 
+// ABI 2: a descriptor names the size of the struct its caller was compiled against; anything else is a caller built against
+// another header (round 2 grew both structs under version 1: the library would read past the end of the old, shorter struct)
+template <class D> static inline bool desc_ok(const D* d) { return d != nullptr && d->struct_size == (int32_t)sizeof(D); }
+#define CTSEG_REQUIRE_DESC(d, name)                                                                                         \
+  CTSEG_REQUIRE(ctseg::desc_ok(d), "%s: descriptor struct_size %d != %d (caller compiled against another ctseg_hip.h; ABI %d)", \
+                name, (d) ? (d)->struct_size : -1, (int)sizeof(*(d)), CTSEG_ABI_VERSION)
+
 static inline bool is16(int dtype) { return dtype == CTSEG_BF16 || dtype == CTSEG_F16; }   // 16-bit storage kinds
 
 static inline int ilog_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

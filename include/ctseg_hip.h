@@ -23,7 +23,10 @@
 extern "C" {
 #endif
 
-#define CTSEG_ABI_VERSION 1
+/* ABI history.  1: round 1.  2: both descriptor structs start with `struct_size` (= sizeof of the struct the CALLER was compiled
+ * against); every entry point that takes a descriptor rejects a size it does not know, so a caller built against an older header
+ * can never make the library read past the end of its struct (round 2 appended fields to both structs under version 1). */
+#define CTSEG_ABI_VERSION 2
 #define CTSEG_F32 0
 #define CTSEG_BF16 1
 #define CTSEG_I16 2 /* raw-input dtypes of ctseg_resize3d_to_hwd only */
@@ -51,6 +54,8 @@ typedef struct ctseg_conv_class {
  * Replaces nn.Conv3d / nn.ConvTranspose3d forward and input-gradient inside monai UNet
  * (reference capstone/models/__init__.py:3, built at capstone/volumetric/base_trainer.py:65-72). */
 typedef struct ctseg_conv_desc {
+  int32_t struct_size;   /* sizeof(ctseg_conv_desc) of the caller's header: checked by every entry point (ABI 2)  */
+  int32_t reserved0;     /* 0                                                                                     */
   const void* in;        /* gathered tensor [N][Xi][Yi][Zi][g_ld]                                */
   const void* w;         /* packed weights (ctseg_pack_weights), rows padded to a multiple of 128 */
   const float* bias;     /* [Cn] or NULL                                                         */
@@ -110,6 +115,8 @@ int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream);
  * into `ws`, then ctseg_conv_wgrad_reduce sums them in fixed order (deterministic) into torch layout.
  * Replaces autograd's conv weight/bias backward for the same modules as above. */
 typedef struct ctseg_wgrad_desc {
+  int32_t struct_size;   /* sizeof(ctseg_wgrad_desc) of the caller's header (ABI 2) */
+  int32_t reserved0;
   const void* in;        /* gathered tensor [N][Xi][Yi][Zi][g_ld]  */
   const void* dy;        /* [N][rows][d_ld], rows = Xr*Yr*Zr        */
   float* ws;             /* slabs                                    */

@@ -28,7 +28,8 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_host_side_queries_and_validation():
     L = nat.lib()
-    assert L.ctseg_abi_version() == 1
+    hdr = int(re.search(r"#define CTSEG_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert L.ctseg_abi_version() == hdr == nat.ABI_VERSION == 2
     assert (L.ctseg_conv_tile_rows(10), L.ctseg_conv_tile_rows(256)) == (256, 128)
     assert [L.ctseg_conv_tile_cols(c) for c in (10, 32, 64, 256)] == [16, 32, 64, 128]
     assert [L.ctseg_wgrad_tile_cols(c) for c in (10, 32, 64, 256)] == [16, 32, 64, 128]
@@ -37,6 +38,32 @@ def test_host_side_queries_and_validation():
     assert b"null pointer" in L.ctseg_last_error()
     with pytest.raises(nat.NativeError):
         nat.check(-1, "x")
+
+
+def test_descriptors_carry_their_struct_size_and_a_foreign_size_is_rejected():
+    """ABI 2: both descriptor structs start with the sizeof() their caller was compiled against; a caller built against another
+    header (round 2 appended fields under version 1) is refused by every entry point instead of being read past its end."""
+    L = nat.lib()
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for cname, cls in (("ctseg_conv_desc", nat.ConvDesc), ("ctseg_wgrad_desc", nat.WgradDesc)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
+        first = [ln.strip() for ln in body.splitlines() if ln.strip()][0]
+        assert first.startswith("int32_t struct_size"), first
+        assert cls._fields_[0][0] == "struct_size" and cls().struct_size == ctypes.sizeof(cls)
+        # every header field is mirrored, in order (names: `in` is spelled in_ in Python)
+        names = re.findall(r"(?:\*|\s)([A-Za-z_][A-Za-z0-9_]*)(?:\[[A-Z_]+\])?\s*[,;]", body)
+        assert [n if n != "in" else "in_" for n in names] == [f[0] for f in cls._fields_], (cname, names)
+    d = nat.ConvDesc()
+    d.struct_size -= 24                      # "compiled against the round-1 header"
+    assert L.ctseg_conv_igemm(ctypes.byref(d), None) < 0 and b"struct_size" in L.ctseg_last_error()
+    assert L.ctseg_conv_num_tiles(ctypes.byref(d)) < 0
+    assert L.ctseg_conv_split_ok(ctypes.byref(d)) == 0 and L.ctseg_conv_narrow_ok(ctypes.byref(d)) == 0
+    assert L.ctseg_conv_in_norm_ok(ctypes.byref(d)) == 0 and L.ctseg_conv_logits_ce_slots(ctypes.byref(d), 10) == 0
+    w = nat.WgradDesc()
+    w.struct_size += 8
+    assert L.ctseg_conv_wgrad(ctypes.byref(w), None) < 0 and b"struct_size" in L.ctseg_last_error()
+    assert L.ctseg_conv_wgrad_slabs(ctypes.byref(w)) < 0
+    assert L.ctseg_wgrad_narrow_ok(ctypes.byref(w)) == 0 and L.ctseg_wgrad_in_norm_ok(ctypes.byref(w)) == 0
 
 
 def test_product_has_no_cpu_fallback():

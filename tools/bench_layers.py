@@ -30,7 +30,12 @@ def describe(name, args, dt):
         taps = sum(d.cls[i].ntaps for i in range(d.nclass))
         flop = 2.0 * rows * d.Cn * d.Cg * taps
         osz = 4 if d.out_f32 else sz
-        byt = d.N * d.Xi * d.Yi * d.Zi * d.Cg * sz + d.N * d.Xo * d.Yo * d.Zo * d.Cn_store * osz * (2 if d.add else 1)
+        out_b = d.N * d.Xo * d.Yo * d.Zo * d.Cn_store * osz
+        byt = d.N * d.Xi * d.Yi * d.Zi * d.Cg * sz + out_b
+        if d.add and d.add != d.in_:
+            # an addend is a SECOND read stream only when it is another tensor, and then in ITS storage type (fp32 logits take a
+            # 16-bit addend); an identity residual (add == in) is served from the staged operand: 0 algorithmic bytes
+            byt += d.N * d.Xo * d.Yo * d.Zo * d.Cn_store * (4 if d.add_f32 else sz)
         return f"conv Cg={d.Cg:3d} Cn={d.Cn:3d} in={d.Xi}x{d.Yi}x{d.Zi} rows={d.Xr}x{d.Yr}x{d.Zr} cls={d.nclass} s={d.sin}/{d.sout}" \
                f"{' +add' if d.add else ''}{' +stats' if d.stats else ''}{' f32out' if d.out_f32 else ''}", flop, byt
     if name == "ctseg_conv_wgrad":
@@ -102,9 +107,10 @@ def main():
             total += ms
             desc, flop, byt = describe(name, args, plan.dt)
             if ms >= a.min_ms:
+                gbs = byt / ms / 1e6 if byt else 0
                 print(f"{which}:{i:3d} {name[6:]:28s} {ms:8.3f} ms  {flop / ms / 1e9 if flop else 0:7.1f} TF/s  "
-                      f"{byt / ms / 1e6 if byt else 0:7.0f} GB/s(alg)  {desc}")
-    print(f"sum of per-op medians: {total:.2f} ms")
+                      f"{gbs:7.0f} GB/s(alg){' (> HBM peak: operands partly cache-resident)' if gbs > 8000 else ''}  {desc}")
+    print(f"sum of per-op medians: {total:.2f} ms; recorded launches: forward {len(plan.fwd)}, backward {len(plan.bwd)}")
 
 
 if __name__ == "__main__":
