@@ -97,7 +97,8 @@ class BaseUNet2D(_Base):
             self.log(f"Mean Dice Score ({prefix})", dice_mean, on_step=False, on_epoch=True)
 
     def configure_optimizers(self):
-        optimizer = torch.optim.Adam(self.parameters(), lr=self.hparams.lr)
+        from ..optim import Adam            # a torch.optim.Adam whose step() is one launch for the U-Net's flat parameter buffer
+        optimizer = Adam(self.parameters(), lr=self.hparams.lr, unet=self.unet)
         scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="max", factor=0.5, threshold=0.01)
         return {"optimizer": optimizer, "lr_scheduler": scheduler, "monitor": "Mean Dice Score (val)"}
 

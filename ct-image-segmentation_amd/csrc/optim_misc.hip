@@ -210,6 +210,48 @@ extern "C" int ctseg_adam_step(float* p, const float* g, float* m, float* v, int
   return 0;
 }
 
+// x *= host_scale * (dev_scale ? *dev_scale : 1); every block reads the factor and leaves at once when it is exactly 1 (the usual
+// upstream gradient of ``loss.backward()``): the drop-in path pays a ~5 us launch, not a pass over d loss / d logits
+template <typename T> __global__ __launch_bounds__(256) void scale_inplace_kernel(T* __restrict__ x, int64_t n, const float* __restrict__ dev_scale,
+                                                                                    float host_scale) {
+  const float f = host_scale * (dev_scale ? *dev_scale : 1.f);
+  if (f == 1.f) return;
+  constexpr int V = 16 / sizeof(T);
+  const int64_t nv = n / V;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    if constexpr (sizeof(T) == 4) {
+      f32x4 v = reinterpret_cast<f32x4*>(x)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= f;
+      reinterpret_cast<f32x4*>(x)[i] = v;
+    } else {
+      u32x4 v = reinterpret_cast<u32x4*>(x)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned lo = (unsigned)f2bf(bf2f(v[e] & 0xffffu) * f), hi = (unsigned)f2bf(bf2f(v[e] >> 16) * f);
+        v[e] = (lo & 0xffffu) | (hi << 16);
+      }
+      reinterpret_cast<u32x4*>(x)[i] = v;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - nv * V)) {
+    const int64_t i = nv * V + threadIdx.x;
+    if constexpr (sizeof(T) == 4) x[i] *= f;
+    else x[i] = (T)f2bf(bf2f(x[i]) * f);
+  }
+}
+
+extern "C" int ctseg_scale_inplace(void* x, int32_t dtype, int64_t n, const float* dev_scale, float host_scale, void* stream) {
+  CTSEG_REQUIRE(x && n > 0 && (dtype == CTSEG_F32 || dtype == CTSEG_BF16) && ((uintptr_t)x % 16) == 0, "scale_inplace: bad arguments");
+  dim3 grid(nblocks(n / 8 + 1, 2048)), blk(256);
+  if (dtype == CTSEG_F32)
+    hipLaunchKernelGGL(scale_inplace_kernel<float>, grid, blk, 0, (hipStream_t)stream, (float*)x, n, dev_scale, host_scale);
+  else
+    hipLaunchKernelGGL(scale_inplace_kernel<unsigned short>, grid, blk, 0, (hipStream_t)stream, (unsigned short*)x, n, dev_scale, host_scale);
+  CTSEG_LAUNCH_CHECK("scale_inplace");
+  return 0;
+}
+
 extern "C" int ctseg_gather_cast(const float* src, const int32_t* idx, void* dst, int32_t dtype, int64_t n, void* stream) {
   CTSEG_REQUIRE(src && idx && dst && n > 0 && (dtype == CTSEG_F32 || is16(dtype)), "gather_cast: bad arguments");
   if (dtype == CTSEG_F32)

@@ -239,6 +239,13 @@ int ctseg_loss_dice_summary(const double* red, int32_t B, int32_t R, const int64
 int ctseg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     int32_t step, float grad_scale, void* stream);
 
+/* x[0..n) *= host_scale * (dev_scale ? *dev_scale : 1), in place; a launch whose factor is exactly 1 touches no memory.
+ * Two users: the upstream gradient autograd hands ``loss.backward()`` (capstone/volumetric/base_trainer.py:80-82 returns the
+ * loss; Lightning / AMP may scale it) applied to the d loss / d logits the fused loss pass wrote for an upstream gradient of 1,
+ * and the 1 / world of the data-parallel gradient MEAN applied to the all-reduced flat gradient on the drop-in path.
+ * dtype: CTSEG_F32 or CTSEG_BF16. */
+int ctseg_scale_inplace(void* x, int32_t dtype, int64_t n, const float* dev_scale, float host_scale, void* stream);
+
 /* Layout / dtype plumbing. */
 int ctseg_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, void* stream);
 /* fp32 [N][C][S] (torch NC*) -> dtype [N][S][ld] channels-last (pad channels zeroed) and back (fp32 out) */

@@ -283,6 +283,13 @@ class Emulator:
         bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
         P[:] = P - np.float32(lr / bc1) * (M / (np.sqrt(V) / np.float32(np.sqrt(bc2)) + np.float32(eps)))
 
+    def scale_inplace(self, x, dtype, n, dev_scale, host_scale):
+        assert dtype == 0, "the emulator stores fp32 only"
+        f = np.float32(host_scale) * (mem(dev_scale, 1)[0] if dev_scale else np.float32(1))
+        if f != 1:
+            X = mem(x, n)
+            X[:] = X * f
+
     def cast(self, src, sd, dst, dd, n):
         assert sd == F32 and dd == F32
         mem(dst, n)[:] = mem(src, n)

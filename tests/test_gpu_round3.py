@@ -1,0 +1,226 @@
+"""GPU parity tests added in round 3 (run with -m gpu on a MI355X), all through the C ABI:
+  * the data-parallel mean's only HIP arithmetic: ctseg_adam_step with grad_scale != 1 (Lightning DDP's gradient MEAN, reached at
+    capstone/volumetric/base_trainer.py:196) against torch.optim.Adam on the scaled gradient;
+  * BASELINE.json configs[0] AS WRITTEN: BaseUNet2D(filters=[64,128,256,512,1024], use_res_units=True) on one 512 x 512 slice,
+    batch 1, Focal + Dice (capstone/training/base_trainer.py:24-38,72-79), fp32, against the oracle;
+  * optimizer state loaded on the CPU follows the module to the GPU;
+  * MultipleLossWrapper.losses entries called on their own (capstone/models/losses.py:177-180);
+  * --precision 16: fp16 inference plans, bf16 training plans after one warning.
+"""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _dump(name, obj):
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, name), "w") as f:
+            json.dump(obj, f, indent=1)
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("scale", [0.5, 0.125])
+def test_adam_grad_scale_is_adam_on_the_scaled_gradient(scale):
+    """fit_step folds the 1/world of the data-parallel mean into the Adam kernel (grad_scale): the summed gradient stays in the
+    flat buffer, the kernel multiplies on load.  3 steps against torch.optim.Adam fed g * scale (what DDP hands the optimizer)."""
+    from capstone_amd.engine import ParamStore
+    torch.manual_seed(1)
+    n = 100003
+    p0 = torch.randn(n)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    q = torch.nn.Parameter(p0.clone())
+    st = ParamStore([q], torch.device(DEV))
+    for step in range(3):
+        g = torch.randn(n) * (10.0 ** (step - 1))        # summed-over-ranks gradient: three magnitudes
+        ref.grad = g * scale
+        opt.step()
+        st.flat_g[:n].copy_(g.to(DEV))
+        st.adam_step(1e-3, grad_scale=scale)
+        # the kernel must NOT have rescaled the stored gradient (the all-reduced buffer is read by checkpoints / tests afterwards)
+        assert torch.equal(st.flat_g[:n].cpu(), g)
+    np.testing.assert_allclose(q.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(st.adam_m[:n].cpu().numpy(), opt.state[ref]["exp_avg"].numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(st.adam_v[:n].cpu().numpy(), opt.state[ref]["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-12)
+
+
+def test_configs0_as_written_2d_unet_64_to_1024_on_a_512_slice():
+    """BASELINE.json configs[0]: the reference's 2-D path with its DEFAULT widths — 5 filters [64, 128, 256, 512, 1024]
+    (capstone/training/base_trainer.py:24-38), residual units, one 1 x 1 x 512 x 512 slice, Focal + Dice (:28) — forward, losses,
+    Dice metric and backward in fp32 against the oracle.  The first time layers with 512 / 1024 channels (and a 2-D 512 x 512
+    grid) go through the engine.  north_star's bar: logits within 1e-3."""
+    from capstone_amd.training.base_trainer import BaseUNet2D
+    from oracle import losses as OL, metrics as OM
+    from oracle.monai_unet import UNet as OracleUNet
+    torch.manual_seed(12342)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    filters = [64, 128, 256, 512, 1024]
+    ref = OracleUNet(2, 1, 10, filters, (2, 2, 2, 2), num_res_units=2)
+    assert sum(p.numel() for p in ref.parameters()) == 25980905          # Report.pdf p.8, Model L: "26 M"
+    m = BaseUNet2D(filters=list(filters), use_res_units=True, loss_fx=["Focal", "Dice"], transform_degree=0, batch_size=1)
+    m.unet.load_state_dict(ref.state_dict())
+    m.to(DEV)
+    g = torch.Generator().manual_seed(12342)
+    images = torch.randn(1, 1, 512, 512, generator=g)
+    masks = torch.zeros(1, 9, 512, 512, dtype=torch.uint8)
+    for c in range(9):
+        masks[:, c, 40 * c + 30:40 * c + 60, 100 + 20 * c:300 + 10 * c] = 1
+    ind = torch.ones(1, 9)
+    labels = OM.squash_masks(masks, 10)
+    y_ref = ref(images)
+    rv = OL.MultipleLoss(["Dice", "Focal"])(y_ref, labels, ind)
+    total_ref = torch.stack(list(rv.values())).sum()
+    total_ref.backward()
+    batch = (images.to(DEV), masks.to(DEV), ind.to(DEV))
+    loss = m.training_step(batch)
+    logits = m.unet.engine().logits_view().detach().cpu()
+    err = float((logits - y_ref.detach()).abs().max())
+    loss.backward()
+    odice, _ = OM.DiceMetric()(OM.squash_predictions(y_ref.detach()), labels)
+    dice = float(m.logged["Mean Dice Score (train)"])
+    rows = []
+    for (k, p), q in zip(ref.named_parameters(), m.unet.parameters()):
+        a, b = q.grad.cpu().flatten().double(), p.grad.flatten().double()
+        if b.norm() > 1e-5 and not (k.endswith(".bias") and "residual" not in k and ".2.1.conv.unit0" not in k):
+            rows.append((float(torch.dot(a, b) / (a.norm() * b.norm())), float((a - b).norm() / b.norm()), k))
+    worst = sorted(rows)[:5]
+    _dump("configs0_2d_512_fp32_vs_oracle.json", {"logits_max_abs_err": err, "loss": float(loss), "oracle_loss": float(total_ref),
+                                                  "dice": dice, "oracle_dice": float(odice), "parameters": 25980905,
+                                                  "worst_gradient (cos, rel err, tensor)": worst, "tensors_compared": len(rows)})
+    assert err < 1e-3, err
+    np.testing.assert_allclose(float(loss), float(total_ref), rtol=1e-4)
+    assert abs(dice - float(odice)) <= 0.002
+    assert min(rows)[0] > 0.9999, worst
+    # and the no-grad surface on the same weights
+    with torch.no_grad():
+        m.validation_step(batch)
+    np.testing.assert_allclose(m.logged["Dice Loss (val)"].item(), rv["Dice"].item(), rtol=1e-4)
+    np.testing.assert_allclose(m.logged["Focal Loss (val)"].item(), rv["Focal"].item(), rtol=1e-4)
+
+
+def _tiny(precision="fp32", loss_fx=("CrossEntropy",), seed=3):
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    torch.manual_seed(seed)
+    m = BaseUNet3D(filters=[8, 16, 32, 64], loss_fx=list(loss_fx), precision=precision, lr=1e-2)
+    g = torch.Generator().manual_seed(seed + 1)
+    images = torch.randn(2, 1, 32, 32, 16, generator=g)
+    masks = torch.zeros(2, 9, 32, 32, 16, dtype=torch.uint8)
+    for c in range(9):
+        masks[:, c, 3 * c:3 * c + 4, 8:20, 2:10] = 1
+    return m, (images, masks, torch.ones(2, 9))
+
+
+def test_optimizer_state_loaded_on_the_cpu_follows_the_module_to_the_gpu():
+    """Lightning calls on_load_checkpoint while the module is still on the CPU, and load_checkpoint() may run before .to(cuda): the
+    Adam moments and step count sit in a CPU-side flat store then.  Engine.ensure() on the training device must carry them over —
+    resuming with zero moments and a restarted bias correction trains differently and says nothing."""
+    m1, batch = _tiny()
+    sd0 = {k: v.clone() for k, v in m1.state_dict().items()}
+    m1.to(DEV)
+    dbatch = tuple(t.to(DEV) for t in batch)
+    for _ in range(3):
+        m1.fit_step(dbatch)
+    ck = m1.checkpoint()
+    ck = {"state_dict": {k: v.cpu().clone() for k, v in ck["state_dict"].items()}, "hyper_parameters": ck["hyper_parameters"],
+          "optimizer_states": [{"state": {i: {kk: vv.cpu().clone() for kk, vv in e.items()} for i, e in ck["optimizer_states"][0]["state"].items()},
+                                "param_groups": ck["optimizer_states"][0]["param_groups"]}]}
+    m2, _ = _tiny()
+    assert next(m2.parameters()).device.type == "cpu"
+    m2.load_checkpoint(ck)                      # on the CPU
+    assert m2.unet.engine().store.step == 3 and m2.unet.engine().store.flat_p.device.type == "cpu"
+    m2.to(DEV)                                   # ... THEN to the GPU
+    a = [float(m1.fit_step(dbatch)) for _ in range(2)]
+    b = [float(m2.fit_step(dbatch)) for _ in range(2)]
+    st = m2.unet.engine().store
+    assert st.flat_p.device.type == "cuda" and st.step == 5
+    assert a == b, (a, b)                        # same kernels, same state: bit-identical losses
+    assert torch.equal(m1.unet.engine().store.adam_m, st.adam_m) and torch.equal(m1.unet.engine().store.adam_v, st.adam_v)
+    # the Lightning hook route, same order (hook on the CPU, then .to)
+    m3, _ = _tiny()
+    m3.load_state_dict(ck["state_dict"])
+    m3.on_load_checkpoint({"ctseg_native_adam": ck["optimizer_states"][0]})
+    m3.to(DEV)
+    c = [float(m3.fit_step(dbatch)) for _ in range(2)]
+    assert c == a
+    # a model that was never restored really does train differently (the test can tell)
+    m4, _ = _tiny()
+    m4.load_state_dict(ck["state_dict"])
+    m4.to(DEV)
+    m4.fit_step(dbatch)
+    assert float(m4.fit_step(dbatch)) != a[1]
+    del sd0
+
+
+@pytest.mark.parametrize("exclude_missing", [False, True])
+def test_loss_entries_of_the_module_dict_are_callable_on_their_own(exclude_missing):
+    """reference capstone/models/losses.py:177-180: ``self.losses = nn.ModuleDict({name: LOSSES[name](reduction=...)})`` and
+    forward() iterates ``self.losses.items()`` calling ``fx(input, target)`` (:188-195).  Same keys, same call, same values (scalar,
+    or the (B, C-1) / (B, C) table under exclude_missing's reduction="none"), and a gradient w.r.t. the logits."""
+    from capstone_amd.volumetric.losses import MultipleLossWrapper3D
+    from oracle import losses as OL
+    names = ["CrossEntropy", "Dice", "Focal", "GeneralizedDice", "WeightedCrossEntropy"]
+    w = MultipleLossWrapper3D(losses=names, exclude_missing=exclude_missing)
+    assert isinstance(w.losses, torch.nn.ModuleDict) and list(w.losses.keys()) == names
+    assert list(w.state_dict().keys()) == []
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(2, 10, 12, 10, 8, generator=g)
+    target = torch.randint(0, 10, (2, 12, 10, 8), generator=g)
+    ind = torch.ones(2, 9)
+    ol = OL.MultipleLoss(names, exclude_missing=False)
+    for name, fx in w.losses.items():
+        x = logits.clone().to(DEV).requires_grad_(True)
+        v = fx(x, target.to(DEV))
+        xr = logits.clone().requires_grad_(True)
+        table = exclude_missing and name in ("Dice", "Focal", "GeneralizedDice")
+        if table:
+            ref = OL._TABLE[name](xr, target, "none")
+            assert v.shape == ((2, 10) if name == "Focal" else (2, 9)), (name, v.shape)
+            # the mean of the table is the reduced loss
+            np.testing.assert_allclose(v.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=1e-7)
+            coefs = torch.linspace(0.5, 1.5, v.numel()).reshape(v.shape)
+            (v * coefs.to(DEV)).sum().backward()
+            (ref * coefs).sum().backward()
+            np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-3, atol=1e-7)
+        else:
+            assert v.ndim == 0
+            rv = ol(xr, target, ind)[name]
+            np.testing.assert_allclose(float(v), float(rv), rtol=2e-5)
+            v.backward()
+            rv.backward()
+            np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-3, atol=1e-8)
+
+
+def test_precision_16_runs_inference_in_fp16_and_trains_in_bf16_after_one_warning():
+    from capstone_amd import _native as nat
+    m16, batch = _tiny(precision=16)
+    mbf, _ = _tiny(precision="bf16")
+    mbf.load_state_dict(m16.state_dict())
+    m16.to(DEV)
+    mbf.to(DEV)
+    dbatch = tuple(t.to(DEV) for t in batch)
+    with torch.no_grad():
+        y = m16(dbatch[0])
+    assert m16.unet.engine().last_plan.dt == nat.F16 and m16.unet.engine().last_plan.inference
+    with pytest.warns(RuntimeWarning, match="bf16 storage"):
+        l16 = float(m16.fit_step(dbatch))
+    assert m16.unet.engine().last_plan.dt == nat.BF16
+    lbf = float(mbf.fit_step(dbatch))
+    assert l16 == lbf                                  # the same bf16 kernels on the same weights
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m16.fit_step(dbatch)                           # said once
+        with torch.no_grad():
+            y2 = m16(dbatch[0])                        # inference keeps its own fp16 plan (now with updated weights)
+    assert m16.unet.engine().last_plan.dt == nat.F16
+    assert y2.shape == y.shape and not torch.equal(y, y2)

@@ -220,11 +220,93 @@ def test_native_optimizer_state_round_trips_through_torch_adam_layout(emu):
     assert float(l1) == float(l2)
     for p, q in zip(m1.parameters(), m2.parameters()):
         assert torch.equal(p.detach(), q.detach())
-    opt = m2.configure_optimizers()
+    opt = torch.optim.Adam(m2.parameters(), lr=m2.hparams.lr)
     opt.load_state_dict(m2.optimizer_state_dict())                   # torch's own Adam takes the layout
     st = m2.unet.engine().store
     p0 = next(iter(m2.parameters()))
     assert torch.equal(opt.state[p0]["exp_avg"].reshape(-1), st.adam_m[st.off(p0):st.off(p0) + p0.numel()])
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_drop_in_surface_training_step_backward_optimizer_step_equals_fit_step(emu, monkeypatch, fused):
+    """The surface the reference's Lightning loop drives (capstone/volumetric/base_trainer.py:80-82,113-114): ``training_step`` ->
+    ``loss.backward()`` -> ``configure_optimizers().step()`` -> ``zero_grad()``.  With a cross-entropy-only loss the step runs
+    fused (plan._StepLossFn), ``p.grad`` is a view of the flat gradient buffer (no copies) and the optimizer is one ctseg_adam_step
+    launch — and the weights after K steps are BIT-identical to K ``fit_step`` calls, for both zero_grad conventions, for an upstream
+    gradient != 1, and with gradient accumulation (two backwards, one step) equal to the oracle."""
+    from capstone_amd.optim import Adam
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    import oracle.trainer as OT
+    monkeypatch.setenv("CTSEG_DROPIN_FUSED", fused)      # "0": the two-pass route through _shared_step (same results)
+    torch.manual_seed(3)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 1, 8, 8, 8, generator=g)
+    masks = (torch.rand(2, 9, 8, 8, 8, generator=g) < 0.1).to(torch.uint8)
+    batch = (x, masks, torch.ones(2, 9))
+    ref = BaseUNet3D(filters=[4, 8, 16], loss_fx=["CrossEntropy"], lr=1e-2)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    ref_losses = [float(ref.fit_step(batch)) for _ in range(3)]
+    for set_to_none in (True, False):
+        m = BaseUNet3D(filters=[4, 8, 16], loss_fx=["CrossEntropy"], lr=1e-2)
+        m.load_state_dict(sd)
+        opt = m.configure_optimizers()
+        assert isinstance(opt, torch.optim.Adam) and isinstance(opt, Adam) and opt.defaults["lr"] == 1e-2
+        losses = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=set_to_none)
+            loss = m.training_step(batch, 0)
+            assert loss.requires_grad and loss.ndim == 0
+            loss.backward()
+            st = m.unet.engine().store
+            p0 = st.params[0]
+            assert p0.grad.data_ptr() == st.flat_g.data_ptr() + 4 * st.off(p0)        # a view, not a copy
+            opt.step()
+            losses.append(float(loss.detach()))
+        assert losses == ref_losses, (set_to_none, losses, ref_losses)
+        for p, q in zip(ref.parameters(), m.parameters()):
+            assert torch.equal(p.detach(), q.detach())
+        assert m.logged["CrossEntropy Loss (train)"].item() == losses[-1] and "BrainStem Dice (train)" in m.logged
+        # the optimizer's state_dict is torch.optim.Adam's layout, the engine's moments included; it round-trips
+        osd = opt.state_dict()
+        assert len(osd["state"]) == len(list(m.parameters())) and float(osd["state"][0]["step"]) == 3.0
+        plain = torch.optim.Adam(m.parameters(), lr=1e-2)
+        plain.load_state_dict(osd)
+        m2 = BaseUNet3D(filters=[4, 8, 16], loss_fx=["CrossEntropy"], lr=1e-2)
+        m2.load_state_dict(m.state_dict())
+        m2.unet.engine().ensure("cpu")
+        opt2 = m2.configure_optimizers()
+        opt2.load_state_dict(osd)
+        a, b = float(ref.fit_step(batch)), None
+        opt2.zero_grad()
+        l2 = m2.training_step(batch, 0)
+        l2.backward()
+        opt2.step()
+        assert float(l2) == a
+        ref.load_state_dict(m.state_dict())        # rewind the reference model for the next convention
+        ref.load_optimizer_state_dict(osd)
+    # an upstream gradient != 1 and gradient accumulation, against the oracle (torch autograd + torch Adam)
+    om = OT.OracleUNet3D(filters=(4, 8, 16), loss_fx=("CrossEntropy",), lr=1e-2)
+    om.load_state_dict(sd)
+    m = BaseUNet3D(filters=[4, 8, 16], loss_fx=["CrossEntropy"], lr=1e-2)
+    m.load_state_dict(sd)
+    opt, oopt = m.configure_optimizers(), om.configure_optimizers()
+    opt.zero_grad()
+    oopt.zero_grad()
+    (0.25 * m.training_step(batch, 0)).backward()
+    (0.25 * om.training_step(batch)).backward()
+    x2 = torch.randn(2, 1, 8, 8, 8, generator=g)
+    batch2 = (x2, masks, torch.ones(2, 9))
+    (0.75 * m.training_step(batch2, 0)).backward()          # accumulates into the same p.grad
+    (0.75 * om.training_step(batch2)).backward()
+    for (k, p), q in zip(om.named_parameters(), m.parameters()):
+        np.testing.assert_allclose(q.grad.numpy(), p.grad.numpy(), err_msg=k, **_tol(k, p.grad.numpy()))
+    opt.step()
+    oopt.step()
+    if fused == "1":   # a second backward on the same step's graph is refused (its buffers were consumed)
+        loss = m.training_step(batch, 0)
+        loss.backward()
+        with pytest.raises(RuntimeError):
+            loss.backward()
 
 
 def test_epoch_means_and_overwritten_activation_guard(emu):
@@ -302,3 +384,34 @@ def test_identity_residual_bottom_under_a_dense_skip_gradient(emu):
     eng.backward()
     for (k, p), q in zip(ref.named_parameters(), net.parameters()):
         np.testing.assert_allclose(eng.store.grad_view(q).numpy(), p.grad.numpy(), err_msg=k, **_tol(k, p.grad.numpy()))
+
+
+@pytest.mark.parametrize("exclude_missing", [False, True])
+def test_loss_module_dict_entries_match_the_oracle(emu, exclude_missing):
+    """``MultipleLossWrapper.losses`` (reference capstone/models/losses.py:177-180): an nn.ModuleDict keyed by loss name whose
+    entries are called as ``fx(input, target)`` — scalar, or the unreduced (B, C-1) / (B, C) table under ``reduction="none"`` — with
+    a gradient w.r.t. the logits.  Host logic on the C-ABI emulator against the oracle's formulas."""
+    from capstone_amd.volumetric.losses import MultipleLossWrapper3D
+    names = ["CrossEntropy", "Dice", "Focal", "GeneralizedDice", "WeightedCrossEntropy"]
+    w = MultipleLossWrapper3D(losses=names, exclude_missing=exclude_missing)
+    assert isinstance(w.losses, torch.nn.ModuleDict) and list(w.losses.keys()) == names and list(w.state_dict()) == []
+    assert all(fx.reduction == ("none" if exclude_missing else "mean") for fx in w.losses.values())
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(2, 10, 12, 10, 8, generator=g)
+    target = torch.randint(0, 10, (2, 12, 10, 8), generator=g)
+    for name, fx in w.losses.items():
+        x, xr = logits.clone().requires_grad_(True), logits.clone().requires_grad_(True)
+        v = fx(x, target)
+        if exclude_missing and name in ("Dice", "Focal", "GeneralizedDice"):
+            ref = OL._TABLE[name](xr, target, "none")
+            assert v.shape == ref.shape == ((2, 10) if name == "Focal" else (2, 9))
+            np.testing.assert_allclose(v.detach().numpy(), ref.detach().numpy(), rtol=2e-5, atol=1e-7)
+            coefs = torch.linspace(0.5, 1.5, v.numel()).reshape(v.shape)
+            (v * coefs).sum().backward()
+            (ref * coefs).sum().backward()
+        else:
+            ref = OL._TABLE[name](xr, target, "mean")
+            np.testing.assert_allclose(v.item(), ref.item(), rtol=2e-5)
+            v.backward()
+            ref.backward()
+        np.testing.assert_allclose(x.grad.numpy(), xr.grad.numpy(), rtol=2e-3, atol=1e-7)
