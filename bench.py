@@ -106,6 +106,80 @@ def fp32_line(model, batch, steps):
             "loss_last_step": float(loss.item())}
 
 
+def _time_steps(fn, steps, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def drop_in_line(batch, steps, precision):
+    """The surface north_star names, driven the way Lightning 1.0's loop drives the reference (capstone/volumetric/base_trainer.py
+    :80-82,113-114): ``training_step -> loss.backward() -> configure_optimizers().step() -> zero_grad()`` on a fresh module of
+    the same workload, after the main measurement, N=1."""
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    dev = batch[0].device
+    torch.manual_seed(SEED)
+    m = BaseUNet3D(filters=list(FILTERS), loss_fx=["CrossEntropy"], precision=precision, batch_size=batch[0].shape[0]).to(dev)
+    opt = m.configure_optimizers()
+    last = {}
+
+    def step():
+        loss = m.training_step(batch, 0)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        last["loss"] = loss
+
+    ms = _time_steps(step, steps)
+    return {"surface": "training_step -> loss.backward() -> torch.optim.Adam.step() -> zero_grad()", "steps": steps,
+            "ms_per_step": ms, "volumes_per_s": batch[0].shape[0] / (ms * 1e-3), "loss_last_step": float(last["loss"].item()),
+            "optimizer": type(opt).__module__ + "." + type(opt).__name__}
+
+
+def exchange_rehearsal(batch, steps, precision):
+    """Fixed cost of the data-parallel exchange measurable on ONE card: a one-rank RCCL ("nccl") group, the reducer attached with
+    always=True so every collective of the N>1 step is issued (sums are the identity), for both exchange algorithms, against the
+    same module with the exchange off.  Reported under config.dp."""
+    import torch.distributed as dist
+    from capstone_amd import distributed as cdist
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    dev = batch[0].device
+    made = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        made = True
+    out = {"backend": dist.get_backend(), "world": dist.get_world_size(), "steps": steps}
+    torch.manual_seed(SEED)
+    m = BaseUNet3D(filters=list(FILTERS), loss_fx=["CrossEntropy"], precision=precision, batch_size=batch[0].shape[0]).to(dev)
+    m.fit_step(batch, keep_logits=False)
+    out["ms_per_step_exchange_off"] = _time_steps(lambda: m.fit_step(batch, keep_logits=False), steps)
+    prev = os.environ.get("CTSEG_DDP_ALGO")
+    for algo in ("allreduce", "direct"):
+        os.environ["CTSEG_DDP_ALGO"] = algo
+        red = cdist.attach(m, always=True)
+        ms = _time_steps(lambda: m.fit_step(batch, keep_logits=False), steps)
+        pts = red.points_for(m.unet.engine().last_plan)
+        out[f"ms_per_step_exchange_on[{algo}]"] = ms
+        out["chunks"] = len(pts) + 1
+        out["chunk_ends"] = [int(e) for _, e in pts] + [int(red.n)]
+        m.reducer = None
+    if prev is None:
+        os.environ.pop("CTSEG_DDP_ALGO", None)
+    else:
+        os.environ["CTSEG_DDP_ALGO"] = prev
+    out["ms_per_step_exchange_off_after"] = _time_steps(lambda: m.fit_step(batch, keep_logits=False), steps)
+    if made:
+        dist.destroy_process_group()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +191,12 @@ def main():
     ap.add_argument("--fp32-steps", type=int, default=5,
                     help="N=1 only: also time this many steps of the same workload in fp32 storage (the reference's own "
                          "arithmetic) after the main measurement; reported under config.fp32 (0 = skip)")
+    ap.add_argument("--drop-in-steps", type=int, default=20,
+                    help="N=1 only: also time this many steps of training_step -> loss.backward() -> Adam.step() (the reference's "
+                         "own surface) after the main measurement; reported under config.drop_in (0 = skip)")
+    ap.add_argument("--exchange-rehearsal", action="store_true",
+                    help="N=1 only: time the step with the data-parallel exchange issued on a one-rank RCCL group "
+                         "(both CTSEG_DDP_ALGO values) against the exchange off; reported under config.dp")
     ap.add_argument("--cpu-shape", type=int, nargs=4, default=[1, 512, 512, 48])   # one volume = half a batch: ~10 s on 16 host threads
     args = ap.parse_args()
 
@@ -193,6 +273,12 @@ def main():
                                          "NOT the BASELINE.json shape 2x512x512x48")
                                       + "), CrossEntropy + Dice metric + Adam",
                           "global_batch": world * B, "parallelism": f"dp{world}", "loss_last_step": loss_v}}
+        if world > 1:
+            # what a driver needs to verify that RCCL saw N ranks and which exchange ran
+            import torch.distributed as dist
+            red = model.reducer
+            out["config"]["dp"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "algo": red.algo,
+                                   "chunks": len(red.points_for(plan)) + 1, "gradient_bytes": 4 * int(red.n)}
         if ev:
             raw = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)
             ovh = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev)
@@ -228,6 +314,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(tuple(args.cpu_shape), max(1, min(ncpu, 16)))
         if world == 1 and args.fp32_steps > 0 and args.precision == "bf16":
             out["config"]["fp32"] = fp32_line(model, batch, args.fp32_steps)
+        if world == 1 and args.drop_in_steps > 0:
+            out["config"]["drop_in"] = drop_in_line(batch, args.drop_in_steps, args.precision)
+            out["config"]["drop_in"]["fit_step_ms_per_step"] = ms
+        if world == 1 and args.exchange_rehearsal:
+            out["config"]["dp"] = exchange_rehearsal(batch, max(10, min(args.steps, 50)), args.precision)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
