@@ -51,7 +51,8 @@ def test_adam_grad_scale_is_adam_on_the_scaled_gradient(scale):
         # the kernel must NOT have rescaled the stored gradient (the all-reduced buffer is read by checkpoints / tests afterwards)
         assert torch.equal(st.flat_g[:n].cpu(), g)
     np.testing.assert_allclose(q.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
-    np.testing.assert_allclose(st.adam_m[:n].cpu().numpy(), opt.state[ref]["exp_avg"].numpy(), rtol=1e-5, atol=1e-9)
+    # (the first moment is a difference of terms of the gradient's size: absolute tolerance at fp32 rounding of THAT size)
+    np.testing.assert_allclose(st.adam_m[:n].cpu().numpy(), opt.state[ref]["exp_avg"].numpy(), rtol=1e-5, atol=1e-6 * scale)
     np.testing.assert_allclose(st.adam_v[:n].cpu().numpy(), opt.state[ref]["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-12)
 
 
