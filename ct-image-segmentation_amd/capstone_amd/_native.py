@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libctseg_hip.so")
 
 F32, BF16, I16, U8, F16 = 0, 1, 2, 3, 4      # F16: IEEE half storage, forward (inference) passes only
 MAX_TAPS, MAX_CLASSES = 27, 8
-ABI_VERSION = 2              # CTSEG_ABI_VERSION of include/ctseg_hip.h this binding mirrors
+ABI_VERSION = 3              # CTSEG_ABI_VERSION of include/ctseg_hip.h this binding mirrors
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 _EPC = {F32: 4, BF16: 8, F16: 8}
 _SZ = {F32: 4, BF16: 2, F16: 2}
@@ -68,7 +68,10 @@ class ConvDesc(_SizedDesc):
                 ("stats_ld", C.c_int32), ("stats_tiles", C.c_int32), ("stats_tile0", C.c_int32),
                 ("nclass", C.c_int32), ("cls", ConvClass * MAX_CLASSES),
                 ("out2", C.c_void_p), ("out2_col0", C.c_int32), ("o2_ld", C.c_int32),
-                ("in_mean_rstd", C.c_void_p), ("in_alpha", C.c_void_p), ("in_norm_C", C.c_int32)]
+                ("in_mean_rstd", C.c_void_p), ("in_alpha", C.c_void_p), ("in_norm_C", C.c_int32),
+                ("bst_y", C.c_void_p), ("bst_mean_rstd", C.c_void_p), ("bst_alpha", C.c_void_p), ("bst_partials", C.c_void_p),
+                ("bst_y_ld", C.c_int32), ("bst_C", C.c_int32), ("bst_col0", C.c_int32), ("bst_P", C.c_int32), ("bst_ld", C.c_int32),
+                ("reserved1", C.c_int32)]
 
 
 class WgradDesc(_SizedDesc):
@@ -92,6 +95,7 @@ _SIGS = {
     "ctseg_conv_narrow_ok": (C.c_int, [C.POINTER(ConvDesc)]),
     "ctseg_wgrad_narrow_ok": (C.c_int, [C.POINTER(WgradDesc)]),
     "ctseg_conv_in_norm_ok": (C.c_int, [C.POINTER(ConvDesc)]),
+    "ctseg_conv_bwd_stats_slots": (C.c_int, [C.POINTER(ConvDesc)]),
     "ctseg_wgrad_in_norm_ok": (C.c_int, [C.POINTER(WgradDesc)]),
     "ctseg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "ctseg_wgrad_tile_cols": (C.c_int, [_i32]),

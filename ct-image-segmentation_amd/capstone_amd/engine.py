@@ -32,11 +32,14 @@ def rup(a, b):
 
 class Act:
     """Channels-last activation handle: tensor [N,X,Y,Z,ld], C valid channels starting at c0."""
-    __slots__ = ("t", "C", "c0", "dt", "pending_norm")
+    __slots__ = ("t", "C", "c0", "dt", "pending_norm", "bst")
 
     def __init__(self, t, C, c0=0, dt=None):
         self.t, self.C, self.c0 = t, C, c0
         self.pending_norm = None      # a _NormAct whose InstanceNorm + PReLU the consumers of this raw conv output apply on load
+        # a GRADIENT tensor whose producing pass already took the backward statistics of the norm it feeds in its epilogue
+        # (ctseg_conv_desc::bst_*): (norm, partials, P, ld) — that norm's backward then skips its reduce pass
+        self.bst = None
         self.dt = dt if dt is not None else {torch.float32: F32, torch.float16: nat.F16}.get(t.dtype, BF16)
 
     @property
@@ -56,7 +59,11 @@ class Act:
         return self.t.data_ptr() + self.c0 * self.t.element_size()
 
     def slice(self, c0, C):
-        return Act(self.t, C, self.c0 + c0, self.dt)
+        a = Act(self.t, C, self.c0 + c0, self.dt)
+        b = self.bst
+        if b is not None and b[0] == "slice" and b[1] == c0 and b[2] == C:
+            a.bst = b[3]              # the column range whose backward statistics the producing pass took
+        return a
 
     def valid(self):
         """torch view of the valid channels, logical NC[XYZ] order"""
@@ -377,8 +384,34 @@ class GemmLayer:
         plan.emit("ctseg_conv_igemm", d, keep=(x, out, add, stats))
         return out, stats
 
-    def emit_dgrad(self, dy, out=None, add=None, split_at=None):
-        """input gradient: gathered = dY (Cn channels), written = dX (cin channels)"""
+    def _try_bst(self, d, out, norm, col0=0):
+        """ask the pass that writes the gradient ``out`` to take the backward statistics of ``norm`` (the InstanceNorm + PReLU whose
+        output gradient ``out`` is, channels [col0, col0 + C) of the pass) in its epilogue; returns the tensor the statistics
+        belong to (``out``, or the second half of a split output) or None when the kernel taking the pass cannot"""
+        if norm is None or os.environ.get("CTSEG_BST", "1") == "0":
+            return None       # (the library declines fp32 storage: its trajectory tests pin a summation order)
+        y = norm.y
+        tgt = out.slice(col0, y.C) if (col0 or isinstance(out, SplitAct)) else out
+        if tgt.C != y.C or tgt.dims != y.dims:
+            return None
+        d.bst_y, d.bst_y_ld, d.bst_C, d.bst_col0 = y.ptr(), y.ld, y.C, col0
+        P = nat.query("ctseg_conv_bwd_stats_slots", d)
+        if P <= 0:
+            d.bst_y, d.bst_y_ld, d.bst_C, d.bst_col0 = None, 0, 0, 0
+            return None
+        plan = self.plan
+        ld = rup(y.C, 4)
+        part = torch.zeros((y.dims[0], P, 3, ld), dtype=torch.float32, device=plan.device)
+        d.bst_mean_rstd, d.bst_alpha = norm.mr.data_ptr(), plan.store.p_ptr(norm.alpha)
+        d.bst_partials, d.bst_P, d.bst_ld = part.data_ptr(), P, ld
+        tgt.bst = (norm, part, P, ld)
+        if tgt is not out and not isinstance(out, SplitAct):
+            out.bst = ("slice", col0, y.C, tgt.bst)      # slices of a plain Act are made afresh: the parent remembers the mark
+        return tgt
+
+    def emit_dgrad(self, dy, out=None, add=None, split_at=None, bst=None, bst_col0=0):
+        """input gradient: gathered = dY (Cn channels), written = dX (cin channels).  ``bst``: the _NormAct whose backward consumes
+        the written gradient (its channels [bst_col0, ..)): its statistics are taken in this pass's epilogue where the kernel can"""
         plan = self.plan
         assert self.dg_pack is not None, f"{self.name}: built without an input-gradient operand"
         xd = self.x_dims
@@ -399,7 +432,8 @@ class GemmLayer:
             sp = self._try_split(d, xd, split_at)
             if sp is not None:
                 out = sp
-        plan.emit("ctseg_conv_igemm", d, keep=(dy, out, add))
+        marked = self._try_bst(d, out, bst, bst_col0)
+        plan.emit("ctseg_conv_igemm", d, keep=(dy, out, add, marked.bst[1] if marked is not None else None, bst.y if marked is not None else None))
         return out
 
     def emit_wgrad(self, x, dy, bias_done=False):

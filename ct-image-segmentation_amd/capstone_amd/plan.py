@@ -82,13 +82,20 @@ class _NormAct:
         if nat.is16(plan.dt):      # (fp32 storage keeps its partition: the 40-step fp32 trajectory test pins a summation order)
             P = max(P, min(math.ceil(1024 / N), math.ceil(S / 32)))
         ld = rup(C, 4)
-        part = torch.zeros((N, P, 3, ld), dtype=torch.float32, device=plan.device)
         sums = torch.zeros((N, C, 2), dtype=torch.float32, device=plan.device)
         if dy_out is None:
             dy_out = new_act(*y.dims, C, plan.dt, plan.device)
         a_ptr = plan.store.p_ptr(self.alpha)
-        plan.emit("ctseg_instnorm_prelu_bwd_reduce", plan.dt, g.ptr(), g.ld, y.ptr(), y.ld, self.mr.data_ptr(), a_ptr,
-                  part.data_ptr(), P, ld, N, S, C, keep=(g, part))
+        mark = getattr(g, "bst", None)
+        fused = mark is not None and mark[0] is self
+        plan.norm_bwd.append((sums, fused))        # (tests: the statistics of every norm's backward, and where they came from)
+        if fused:
+            # the pass that wrote g took the three sums in its epilogue (ctseg_conv_desc::bst_*): no reduce pass, no second read of g
+            _, part, P, ld = mark
+        else:
+            part = torch.zeros((N, P, 3, ld), dtype=torch.float32, device=plan.device)
+            plan.emit("ctseg_instnorm_prelu_bwd_reduce", plan.dt, g.ptr(), g.ld, y.ptr(), y.ld, self.mr.data_ptr(), a_ptr,
+                      part.data_ptr(), P, ld, N, S, C, keep=(g, part))
         da_part = torch.zeros(N * C + 1, dtype=torch.float64, device=plan.device)
         # the slope-gradient sum over da_part rides on the apply pass below (one of its workgroups; no launch, no atomics)
         plan.emit("ctseg_instnorm_prelu_bwd_finalize", part.data_ptr(), N, P, ld, C, float(S), da_part.data_ptr(), sums.data_ptr(),
@@ -127,7 +134,13 @@ class _ConvBlock:
             return self.na.defer(y, stats)
         return self.na.emit_fwd(y, stats, 0, None, out)
 
-    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True, split_at=None):
+    def first_bwd_norm(self):
+        """the norm whose backward consumes the gradient handed to emit_bwd first (None: a convolution does)"""
+        return self.na
+
+    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True, split_at=None, bst=None, bst_col0=0):
+        """bst: the _NormAct that consumes the returned gradient (its channels from bst_col0 on) — its backward statistics are taken
+        by the pass that writes that gradient where the kernel can (GemmLayer.emit_dgrad)"""
         bias = self.mod.conv.bias
         fuse_bias = self.na is not None and self.gemm.transposed and bias is not None
         if self.na is None:
@@ -146,7 +159,7 @@ class _ConvBlock:
         self.plan.grads_ready(self.params)
         if not need_dx:
             return None
-        return self.gemm.emit_dgrad(dy, out=out, add=_addend(out, accumulate), split_at=split_at)
+        return self.gemm.emit_dgrad(dy, out=out, add=_addend(out, accumulate), split_at=split_at, bst=bst, bst_col0=bst_col0)
 
 
 class _ResUnit:
@@ -201,8 +214,11 @@ class _ResUnit:
             cur = na.emit_fwd(y, stats, col0, res if last else None, out if last else None)
         return cur
 
-    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True):
-        """g = dL/d(out).  out = last_activation + res  =>  both receive g."""
+    def first_bwd_norm(self):
+        return self.nas[-1]
+
+    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True, bst=None):
+        """g = dL/d(out).  out = last_activation + res  =>  both receive g.  bst: see _ConvBlock.emit_bwd."""
         plan, C = self.plan, self.mod.cout
         n = len(self.units)
         d = g
@@ -227,7 +243,7 @@ class _ResUnit:
                 break
             gm.emit_wgrad(self.inputs[i], dy)
             plan.grads_ready([gm.parts[0][0], gm.parts[0][1]] + ([na.alpha] if na is not None else []))
-            d = gm.emit_dgrad(dy)
+            d = gm.emit_dgrad(dy, bst=self.nas[i - 1])
         # ---- unit0 (+ residual branch) ----
         na0 = self.nas[0]
         alpha0 = [na0.alpha] if na0 is not None else []
@@ -236,7 +252,7 @@ class _ResUnit:
             plan.grads_ready([p for w, b, _ in self.fused.parts for p in (w, b)] + alpha0)
             if not need_dx:
                 return None
-            return self.fused.emit_dgrad(dfused, out=out, add=_addend(out, accumulate))
+            return self.fused.emit_dgrad(dfused, out=out, add=_addend(out, accumulate), bst=bst)
         g0 = self.gemms[0]
         g0.emit_wgrad(self.x, dy)
         ready = [g0.parts[0][0], g0.parts[0][1]] + alpha0
@@ -248,7 +264,7 @@ class _ResUnit:
             return None
         if self.identity:
             if not accumulate:
-                return g0.emit_dgrad(dy, out=out, add=g)        # dx = g + dgrad(dy)
+                return g0.emit_dgrad(dy, out=out, add=g, bst=bst)        # dx = g + dgrad(dy)
             # identity residual AND an accumulated target (a bottom block with equal channel counts under a dense skip gradient):
             # dx = g + dgrad(dy) into a fresh tensor, then one elementwise pass adds the accumulated term
             tmp = g0.emit_dgrad(dy, add=g)
@@ -258,8 +274,10 @@ class _ResUnit:
             plan.emit("ctseg_instnorm_prelu_fwd", plan.dt, tmp.ptr(), tmp.ld, None, None, acc.ptr(), acc.ld, out.ptr(), out.ld,
                       tmp.dims[0], tmp.S, tmp.C, keep=(tmp, acc, out))       # mean_rstd = NULL: out = tmp + acc
             return out
+        if self.res_gemm is None:
+            return g0.emit_dgrad(dy, out=out, add=_addend(out, accumulate), bst=bst)
         dx = g0.emit_dgrad(dy, out=out, add=_addend(out, accumulate))
-        return self.res_gemm.emit_dgrad(g, out=dx, add=dx)      # += dgrad of the 1x1 residual conv
+        return self.res_gemm.emit_dgrad(g, out=dx, add=dx, bst=bst)      # += dgrad of the 1x1 residual conv (the pass that completes dx)
 
 
 class _Level:
@@ -309,7 +327,10 @@ class _Level:
         a = self.up0.emit_fwd(self.cat, defer_norm=head)
         return self.up1.emit_fwd(a, out=out, out_f32=out_f32)
 
-    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True, depth=0):
+    def first_bwd_norm(self):
+        return self.up1.first_bwd_norm() if self.up1 is not None else self.up0.first_bwd_norm()
+
+    def emit_bwd(self, g, out=None, accumulate=False, need_dx=True, depth=0, bst=None):
         plan = self.plan
         # The head's weight gradients (HBM-bound, 1.2 ms of side-stream work) are not queued beside the head's own HBM-bound
         # input-gradient / norm-backward passes but when the backward reaches level `defer_to`, whose passes are MFMA-bound:
@@ -323,22 +344,24 @@ class _Level:
             plan._defer, plan._stash = plan._stash, None
             plan.flush_deferred()
         if self.up1 is not None:
-            g = self.up1.emit_bwd(g)
-        gcat = self.up0.emit_bwd(g, split_at=self.c1)      # [d(skip) | d(sub output)], as two dense tensors where the kernel can
+            g = self.up1.emit_bwd(g, bst=self.up0.first_bwd_norm())
+        # [d(skip) | d(sub output)], as two dense tensors where the kernel can; the second half feeds the sub-block's last norm
+        gcat = self.up0.emit_bwd(g, split_at=self.c1, bst=self.sub.first_bwd_norm(), bst_col0=self.c1)
         if self.is_top and defer_to > 0:
             plan._stash, plan._defer = plan._defer, None     # only the head's weight gradients wait
         # d(skip) = gcat[:, :c1] + d(sub input).  The sum goes to a DENSE tensor (the addend is read from the concat-gradient
         # slice): the norm-backward passes of the down block then stream full cache lines instead of half of every line
         if os.environ.get("CTSEG_DENSE_SKIP_GRAD", "1") != "0":
             kw = {"depth": depth + 1} if isinstance(self.sub, _Level) else {}
-            gskip = self.sub.emit_bwd(gcat.slice(self.c1, self.c2), out=None, accumulate=gcat.slice(0, self.c1), **kw)
+            gskip = self.sub.emit_bwd(gcat.slice(self.c1, self.c2), out=None, accumulate=gcat.slice(0, self.c1),
+                                      bst=self.down.first_bwd_norm(), **kw)
         else:
             self.sub.emit_bwd(gcat.slice(self.c1, self.c2), out=gcat.slice(0, self.c1), accumulate=True)
             gskip = gcat.slice(0, self.c1)
         if self.is_top and getattr(plan, "_stash", None):     # never flushed below (fewer levels than asked for)
             plan._defer, plan._stash = plan._stash, None
             plan.flush_deferred()
-        return self.down.emit_bwd(gskip, out=out, accumulate=accumulate, need_dx=need_dx)
+        return self.down.emit_bwd(gskip, out=out, accumulate=accumulate, need_dx=need_dx, bst=bst)
 
 
 def _make_side_stream(device):
@@ -383,6 +406,7 @@ class Plan:
         cin = net.in_channels
         self.root = _Level(self, net.model, "model", cin, True)
         self.packer.finalize()
+        self.norm_bwd = []
         # ---- record programs ----
         self.x = Act(torch.zeros((N, X, Y, Z, cin), dtype=nat.torch_dtype(self.dt), device=self.device), cin, 0, self.dt)
         self._cur = self.fwd

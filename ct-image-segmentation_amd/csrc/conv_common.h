@@ -4,6 +4,24 @@
 
 namespace ctseg {
 
+// Backward InstanceNorm statistics taken in the epilogue of the pass that writes the gradient (ctseg_conv_desc::bst_*): the three
+// sums instnorm_prelu_bwd_reduce_kernel (norm_act.hip) computes in a pass of its own, term for term the same arithmetic.
+struct BstArgs {
+  const char* y;        // forward conv output the norm normalised, indexed like the written tensor; channel c <-> GEMM column col0 + c
+  const float* mr;      // [N][C][2] (mean, rstd)
+  const float* alpha;   // PReLU slope
+  float* part;          // [N][P][3][ld] fp32, one row per workgroup (or tile) and sample; nullptr: off
+  int y_ld, C, col0, P, ld;
+};
+
+__device__ __forceinline__ void bst_term(float g, float yv, float mean, float rstd, float al, float& a1, float& a2, float& a3) {
+  const float xh = (yv - mean) * rstd;
+  const float dxh = g * (xh > 0.f ? 1.f : al);
+  a1 += dxh;
+  a2 += dxh * xh;
+  a3 += xh > 0.f ? 0.f : g * xh;
+}
+
 struct ConvKArgs {
   const char* in;
   const char* w;
@@ -27,7 +45,13 @@ struct ConvKArgs {
   const float* in_mr;
   const float* in_alpha;
   int in_C;
+  BstArgs bst;
 };
+
+static inline void fill_bst(const ctseg_conv_desc* d, ConvKArgs& a) {
+  a.bst.y = (const char*)d->bst_y; a.bst.mr = d->bst_mean_rstd; a.bst.alpha = d->bst_alpha; a.bst.part = d->bst_partials;
+  a.bst.y_ld = d->bst_y_ld; a.bst.C = d->bst_C; a.bst.col0 = d->bst_col0; a.bst.P = d->bst_P; a.bst.ld = d->bst_ld;
+}
 
 // Workgroups reach the 8 XCDs round-robin by linear id.  Tile = (L & 7) * chunk + (L >> 3) gives every XCD one contiguous
 // range of row tiles, so the halo rows neighbouring tiles share are fetched by ONE L2 instead of by all eight.  -1: no tile.
@@ -192,6 +216,7 @@ void launch_conv_halo(ConvKArgs& a, int dtype, hipStream_t st);
 // weights in registers (taken first where eligible)
 bool conv_halo_x_eligible(const ConvKArgs& a, int dtype, int nclass);
 bool conv_halo_x_stats_ok(const ConvKArgs& a);
+int conv_halo_x_bst_slots(const ConvKArgs& a);   // 0: this pass cannot take ConvKArgs::bst
 int conv_halo_x_slots(const ConvKArgs& a);
 void launch_conv_halo_x(ConvKArgs& a, hipStream_t st);
 // 8-class stride-2 "up" pass with <= 16 output channels (conv_up_halo.hip): one input tile for all parity classes

@@ -69,6 +69,7 @@ struct XGeom {
   int in_sample_bytes;        // < 2^31 (host-checked)
   int out_sample_bytes;
   int add_sample_bytes;
+  int y_sample_bytes;         // BST: the norm's forward tensor (ConvKArgs::bst.y)
 };
 
 // Cross-entropy fused into the epilogue of the logits convolution (CE = true): the fp32 logits never leave the registers.  What
@@ -99,8 +100,13 @@ struct XCe {
 // R12: the gathered rows are 12 elements wide (24 bytes: the 10-class tensors of the head): such a row cannot be moved in 16-byte DMA
 // pieces, so the halo is staged through registers in 8-byte pieces (buffer loads with the same out-of-range trick, then
 // ds_write_b64 into the same two-plane LDS image; the upper half of every plane-1 slot is zeroed once and never written again).
-template <typename H, int VB, int NT, int NS, bool FLIP, bool STATS, int ADD, bool OF32, bool R12, bool CE = false>
-__global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P, const XGeom G, int total_tiles, const XCe E) {
+// BST: backward InstanceNorm statistics of the written gradient (ConvKArgs::bst).  Plane i of a tile's epilogue reads the y values of
+// its four channels from registers that were loaded ONE TILE AHEAD (right behind the previous tile's store of the same plane: a
+// load consumed in the tile it is issued in puts an HBM round trip on every tile), and accumulates the three sums per lane; they
+// are combined per workgroup at every sample change, as the forward statistics are.
+template <typename H, int VB, int NT, int NS, bool FLIP, bool STATS, int ADD, bool OF32, bool R12, bool CE = false, bool BST = false>
+__global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) void conv_halo_x_kernel(const ConvKArgs P, const XGeom G, int total_tiles, const XCe E) {
+  static_assert(!BST || (!STATS && !OF32 && !CE && ADD != 2), "backward statistics: 16-bit gradient passes without a global-memory addend");
   static_assert(!R12 || (VB == 32 && NS == 1), "12-wide rows: 16 gathered channels, one wave group");
   static_assert(!CE || (VB == 32 && NS == 1 && NT == 1 && !FLIP && !STATS && ADD < 2), "fused cross-entropy: the logits convolution");
   static_assert(ADD != 3 || (!R12 && !CE), "DMA-staged addend: the DMA pipeline only");
@@ -126,13 +132,16 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
   constexpr int CE_B = CE ? 3 * 16 * 4 + NW * 2 * 8 : 0;     // Dice counters, per-wave loss sums
   constexpr int NRM_B = R12 ? X_NRM_MAXN * 96 : 0;           // operand normalisation: per sample 3 channel quads x (mean x 4, rstd x 4)
   constexpr int CE_L = CE ? NW * 3 * 6 * 64 * 4 : 0;         // per-LANE Dice counters: [wave][kind][class pair][lane], two 16-bit fields per word
-  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B + 2 * ABUF + NRM_B + CE_L];
-  char* const sLaneBase = smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B + 2 * ABUF + NRM_B;
-  char* const sA = smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B;
-  float* const sPar = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4 + CE_T + CE_B + 2 * ABUF);
+  constexpr int ST_B = NW * (BST ? 3 : 2) * 16 * NT * 4;     // per-wave statistics slots (forward: sum, sum of squares; BST: three sums)
+  constexpr int BT_B = BST ? 16 * NTA * 2 * 4 : 0;           // BST: (mean x 4, rstd x 4) per channel quad of the current sample
+  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + 2 * ABUF + NRM_B + CE_L + BT_B];
+  float* const sBt = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + 2 * ABUF + NRM_B + CE_L);
+  char* const sLaneBase = smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + 2 * ABUF + NRM_B;
+  char* const sA = smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B;
+  float* const sPar = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + 2 * ABUF);
   char* const sW = smem + 2 * CF::HALO;
   float* const sStats = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES);     // per-wave statistics slots
-  char* const sT = smem + 2 * CF::HALO + WBYTES + NW * 2 * 16 * NT * 4;
+  char* const sT = smem + 2 * CF::HALO + WBYTES + ST_B;
   unsigned int* const sCnt = reinterpret_cast<unsigned int*>(sT + CE_T);
   double* const sSum = reinterpret_cast<double*>(sT + CE_T + 3 * 16 * 4);
 
@@ -222,20 +231,29 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
   // R12 staging: 3 eight-byte pieces per halo voxel (bytes 0-7, 8-15 -> plane 0; 16-23 -> plane 1), voxel-major so that a wave's
   // loads run along the 240-byte z rows of the volume
   constexpr int R_N = X_HV * 3, R_J = R12 ? (R_N + NTHR - 1) / NTHR : 1;
-  int roff[R_J], rlds[R_J];
-  uint32_t rhot[R_J];
+  // the constants of the last round (8 pieces of 1800 at 256 threads) are recomputed where they are used instead of held in three
+  // registers by every lane through the multiplies (BST: the kernel sits at the 256-register line of two waves per SIMD)
+  constexpr int R_JC = (R12 && BST && R_N % NTHR != 0) ? R_J - 1 : R_J;
+  int roff[R_JC], rlds[R_JC];
+  uint32_t rhot[R_JC];
+  auto piece_consts = [&](int idx, int& off, uint32_t& hot, int& lds) {
+    const int hv = idx / 3, part = idx - hv * 3;
+    const int hx = hv / (X_HY * X_HZ), rem = hv - hx * (X_HY * X_HZ);
+    const int hy = rem / X_HZ, hz = rem - hy * X_HZ;
+    off = (hx * YZ + hy * P.Zi + hz) * P.g_ld * 2 + part * 8;
+    hot = idx < R_N ? ((1u << hx) | (1u << (6 + hy)) | (1u << (16 + hz))) : 0x80000000u;
+    lds = (part == 2 ? X_PLANE : 0) + hv * 16 + (part == 1 ? 8 : 0);
+  };
   if constexpr (R12) {
 #pragma unroll
-    for (int j = 0; j < R_J; ++j) {
-      const int idx = tid + j * NTHR;
-      const int hv = idx / 3, part = idx - hv * 3;
-      const int hx = hv / (X_HY * X_HZ), rem = hv - hx * (X_HY * X_HZ);
-      const int hy = rem / X_HZ, hz = rem - hy * X_HZ;
-      roff[j] = (hx * YZ + hy * P.Zi + hz) * P.g_ld * 2 + part * 8;
-      rhot[j] = idx < R_N ? ((1u << hx) | (1u << (6 + hy)) | (1u << (16 + hz))) : 0x80000000u;
-      rlds[j] = (part == 2 ? X_PLANE : 0) + hv * 16 + (part == 1 ? 8 : 0);
-    }
+    for (int j = 0; j < R_JC; ++j) piece_consts(tid + j * NTHR, roff[j], rhot[j], rlds[j]);
   }
+  auto piece = [&](int j, int& off, uint32_t& hot, int& lds) {
+    if (j < R_JC) { off = roff[j]; hot = rhot[j]; lds = rlds[j]; return; }
+    int t = tid;
+    asm volatile("" : "+v"(t));          // (opaque: keeps the recomputation from being hoisted out of the tile loop into registers)
+    piece_consts(t + j * NTHR, off, hot, lds);
+  };
   const int bias_bytes = (YZ + P.Zi + 1) * P.g_ld * 2;    // the halo origin of a tile at x0 = y0 = z0 = 0 lies this far before the sample
   // output: per-lane byte offset of (plane 0, this lane's voxel, its 4 channels of column block 0) from the tile's first voxel
   const int chn = col0 + 4 * q4;
@@ -253,7 +271,7 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bias[j][e] = (P.bias != nullptr && chn + 16 * j + e < P.Cn) ? P.bias[chn + 16 * j + e] : 0.f;
+    for (int e = 0; e < 4; ++e) bias[j][e] = (!BST && P.bias != nullptr && chn + 16 * j + e < P.Cn) ? P.bias[chn + 16 * j + e] : 0.f;   // (BST: a gradient pass, no bias: host-checked)
 
   float wsum[NT][4], wsq[NT][4];
 #pragma unroll
@@ -288,6 +306,66 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     __syncthreads();
   };
 
+  // ---- BST: per-lane sums of the lane's 4 channels (x NT column blocks), constants of the current sample -----------------------
+  // (the third sum feeds the gradient of the ONE PReLU slope: only its total over channels matters, so a lane keeps one accumulator
+  // for its four channels and reports it under the first of them)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  float b1[NT][4], b2[NT][4], b3[NT];
+  u32x2 yreg[NT][X_TX];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    b3[j] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { b1[j][e] = b2[j][e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < X_TX; ++i) yreg[j][i] = u32x2{0u, 0u};
+  }
+  const float bal = BST ? P.bst.alpha[0] : 1.f;
+  int bst_n = -1;
+  bool ych_ok[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) ych_ok[j] = BST && chn + 16 * j >= P.bst.col0 && chn + 16 * j - P.bst.col0 < P.bst.C;
+  // the constants of the current sample live in LDS (a lane's 4 channels: two broadcast 16-byte reads per slice), not in registers
+  // the multiplies' operand prefetch needs; rstd = 0 marks a column that is not a channel of the norm
+  auto bst_consts = [&](int n) {       // (called by every thread, between the barriers of flush_bst or before the first tile's)
+    if (tid < 16 * NTA * 2) {
+      const int col = tid >> 1, which = tid & 1;
+      const int c = blockIdx.y * (16 * NTA) + col - P.bst.col0;
+      const bool ok = c >= 0 && c < P.bst.C;
+      // (rstd x 4, -mean * rstd x 4) per channel quad: xhat = fma(y, rstd, -mean * rstd)
+      const float mean = ok ? P.bst.mr[((int64_t)n * P.bst.C + c) * 2] : 0.f, rstd = ok ? P.bst.mr[((int64_t)n * P.bst.C + c) * 2 + 1] : 0.f;
+      sBt[(col >> 2) * 8 + which * 4 + (col & 3)] = which == 0 ? rstd : -mean * rstd;
+    }
+    __syncthreads();
+  };
+  auto flush_bst = [&](int n) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = b1[j][e], b = b2[j][e], c = e == 0 ? b3[j] : 0.f;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); if (e == 0) c += __shfl_xor(c, o, 64); }
+        if (r16 == 0) {
+          sStats[(wave * 3 + 0) * 16 * NT + j * 16 + 4 * q4 + e] = a;
+          sStats[(wave * 3 + 1) * 16 * NT + j * 16 + 4 * q4 + e] = b;
+          sStats[(wave * 3 + 2) * 16 * NT + j * 16 + 4 * q4 + e] = c;
+        }
+        b1[j][e] = 0.f; b2[j][e] = 0.f;
+        if (e == 0) b3[j] = 0.f;
+      }
+    __syncthreads();
+    if (tid < 3 * 16 * NTA) {
+      const int which = tid / (16 * NTA), c = tid % (16 * NTA), grp = c / (16 * NT), cc = c % (16 * NT);
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) a += sStats[((grp * 4 + w) * 3 + which) * 16 * NT + cc];
+      const int ch = blockIdx.y * (16 * NTA) + c - P.bst.col0;
+      if (ch >= 0 && ch < P.bst.C) P.bst.part[(((int64_t)n * P.bst.P + blockIdx.x) * 3 + which) * P.bst.ld + ch] = a;
+    }
+    __syncthreads();
+  };
+
   struct Org { int n, x0, y0, z0; };
   auto tile_origin = [&](int t) -> Org {
     Org o;
@@ -303,7 +381,10 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     hi = hi > nbits - 1 ? nbits - 1 : hi;
     return hi < lo ? 0u : ((2u << hi) - (1u << lo));
   };
-  auto dma = [&](const Org& o, int buf) {
+  // live = false (BST only): the same vector-memory instructions with every offset out of range.  The compiler's counted waits for
+  // the y registers are the MINIMUM over all paths of the operations issued since their load: with the staging of the next tile
+  // skipped on the last-tile path, every slice of EVERY tile waited for the staging loads just issued (0.40 -> 0.64 ms, head pass)
+  auto dma = [&](const Org& o, int buf, bool live = true) {
     // halo coordinate h of an axis is voxel x0 - 1 + h: inside the volume for h in [1 - x0, Xi - x0]
     const uint32_t m = range_mask(1 - o.x0, P.Xi - o.x0, X_HX) | (range_mask(1 - o.y0, P.Yi - o.y0, X_HY) << 6) |
                        (range_mask(1 - o.z0, P.Zi - o.z0, X_HZ) << 16);
@@ -316,7 +397,7 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
       const int piece = wave + j * NWD;
-      const int vo = (phot[j] & notm) == 0u ? poff[j] : (int)0x80000000;
+      const int vo = (live && (phot[j] & notm) == 0u) ? poff[j] : (int)0x80000000;
       x_raw_buffer_load_lds(rs, (x_lds_u32_ptr)(dst + (piece / X_PIECES) * X_PLANE + (piece % X_PIECES) * 1024), 16, vo, soff, 0, 0);
     }
     if constexpr (ADD == 3) {      // the addend of the same tile, consumed (into registers) at the end of its multiplies
@@ -326,14 +407,14 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
       const int asoff = ((o.x0 * P.Yo + o.y0) * P.Zo + o.z0) * P.add_ld * 2;
 #pragma unroll
       for (int j = 0; j < APW; ++j) {
-        const int vo = (aphot[j] & anot) == 0u ? apoff[j] : (int)0x80000000;
+        const int vo = (live && (aphot[j] & anot) == 0u) ? apoff[j] : (int)0x80000000;
         x_raw_buffer_load_lds(ars, (x_lds_u32_ptr)(sA + buf * ABUF + (wave + j * NW) * 1024), 16, vo, asoff, 0, 0);
       }
     }
   };
 
   u32x2 rg[R_J];
-  auto gload = [&](const Org& o) {
+  auto gload = [&](const Org& o, bool live = true) {
     const uint32_t m = range_mask(1 - o.x0, P.Xi - o.x0, X_HX) | (range_mask(1 - o.y0, P.Yi - o.y0, X_HY) << 6) |
                        (range_mask(1 - o.z0, P.Zi - o.z0, X_HZ) << 16);
     const uint32_t notm = ~m;
@@ -342,7 +423,9 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     const int soff = ((o.x0 * P.Yi + o.y0) * P.Zi + o.z0) * P.g_ld * 2;
 #pragma unroll
     for (int j = 0; j < R_J; ++j) {
-      const int vo = (rhot[j] & notm) == 0u ? roff[j] : (int)0x80000000;
+      int ro, rl; uint32_t rh;
+      piece(j, ro, rh, rl);
+      const int vo = (live && (rh & notm) == 0u) ? ro : (int)0x80000000;
       rg[j] = (X_ABL & 4) ? u32x2{0u, 0u} : __builtin_amdgcn_raw_buffer_load_b64(rs, vo, soff, 0);
     }
   };
@@ -367,8 +450,11 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     char* dst = smem + buf * CF::HALO;
     if (!nrm) {
 #pragma unroll
-      for (int j = 0; j < R_J; ++j)
-        if ((R_J * NTHR == R_N || tid + j * NTHR < R_N) && (!(X_ABL & 128) || rg[j][0] == 0x12345678u)) *reinterpret_cast<u32x2*>(dst + rlds[j]) = rg[j];
+      for (int j = 0; j < R_J; ++j) {
+        int ro, rl; uint32_t rh;
+        piece(j, ro, rh, rl);
+        if ((R_J * NTHR == R_N || tid + j * NTHR < R_N) && (!(X_ABL & 128) || rg[j][0] == 0x12345678u)) *reinterpret_cast<u32x2*>(dst + rl) = rg[j];
+      }
       return;
     }
     const uint32_t notm = ~(range_mask(1 - o.x0, P.Xi - o.x0, X_HX) | (range_mask(1 - o.y0, P.Yi - o.y0, X_HY) << 6) |
@@ -383,9 +469,11 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
         float a = (v[e] - mean[e]) * rstd[e];
         v[e] = a > 0.f ? a : nrm_al * a;
       }
-      const bool inside = (rhot[j] & notm) == 0u;
+      int ro, rl; uint32_t rh;
+      piece(j, ro, rh, rl);
+      const bool inside = (rh & notm) == 0u;
       const u32x2 w = inside ? u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])} : u32x2{0u, 0u};
-      if (R_J * NTHR == R_N || tid + j * NTHR < R_N) *reinterpret_cast<u32x2*>(dst + rlds[j]) = w;
+      if (R_J * NTHR == R_N || tid + j * NTHR < R_N) *reinterpret_cast<u32x2*>(dst + rl) = w;
     }
   };
 
@@ -397,10 +485,29 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     __amdgpu_buffer_rsrc_t ors;
     u32x4 gadd[NT][X_TX];
   };
+  struct Yl { int nx, sbase; bool lane_ok; __amdgpu_buffer_rsrc_t rs; };
+  auto y_head = [&](const Org& o, Yl& y) {           // the tile whose y values the slices fetch (one tile ahead of their use)
+    y.nx = P.Xr - o.x0;
+    y.lane_ok = (o.y0 + 2 * yp + pdy < P.Yr) && (o.z0 + pz < P.Zr);
+    y.sbase = (int)((((int64_t)o.x0 * P.Yo + o.y0) * P.Zo + o.z0) * P.o_ld * 2);       // y is laid out like the written tensor (host-checked)
+    y.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.bst.y) + (int64_t)o.n * G.y_sample_bytes, 0, G.y_sample_bytes, 0x00020000);
+  };
+  auto y_load = [&](const Yl& y, int i) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int vo = (y.lane_ok && ych_ok[j] && i < y.nx) ? ooff + 32 * j : (int)0x80000000;
+      yreg[j][i] = __builtin_amdgcn_raw_buffer_load_b64(y.rs, vo, y.sbase + i * oplane, 0);
+    }
+  };
   auto ep_head = [&](const Org& o, Ep& e) {
     if (STATS && o.n != stat_n) {
       if (stat_n >= 0) flush_stats(stat_n);
       stat_n = o.n;
+    }
+    if (BST && o.n != bst_n) {
+      if (bst_n >= 0) flush_bst(bst_n);
+      bst_n = o.n;
+      bst_consts(o.n);
     }
     e.nx = P.Xr - o.x0;                                          // planes of the tile inside the row grid (may exceed X_TX)
     e.lane_ok = (o.y0 + 2 * yp + pdy < P.Yr) && (o.z0 + pz < P.Zr);
@@ -424,8 +531,20 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
         }
     }
   };
-  auto ep_slice = [&](const Ep& e, const f32x4 (&acc)[NT][X_TX], const u32x2 (&cadd)[NT][X_TX], int i) {
+  Yl ynext;
+  bool y_more = false;          // workgroup-uniform: the slices fetch the y values of the tile being multiplied
+  // R12 && ADD == 1: the halo of the tile whose epilogue runs is still intact while the next tile multiplies (the register-staged
+  // pipeline stores the tile after next only behind those multiplies), so a slice reads its identity-residual addend from there
+  // instead of carrying 2 x 8 registers of centre voxels through the multiplies
+  constexpr bool CADD_LATE = R12 && ADD == 1 && !CE;
+  auto ep_slice = [&](const Ep& e, const f32x4 (&acc)[NT][X_TX], const u32x2 (&cadd_)[NT][X_TX], int i, int hbuf) {
     const bool ok = e.lane_ok && i < e.nx;
+    u32x2 cadd[NT][X_TX];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if constexpr (CADD_LATE) cadd[j][i] = *reinterpret_cast<const u32x2*>(smem + hbuf * CF::HALO + cbase + 2 * j * X_PLANE + i * X_XSTRIDE);
+      else cadd[j][i] = cadd_[j][i];
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       float v[4];
@@ -458,9 +577,38 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
         // epilogue lost 16-bit elements to a v_mov scheduled right behind such a store); keep the data registers live for two wait states
         asm volatile("s_nop 1" ::"v"(o4));
       } else {
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])}, e.ors, vo, e.sbase + i * oplane, 0);
+        const u32x2 o2 = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(o2, e.ors, vo, e.sbase + i * oplane, 0);
+        if constexpr (BST) {
+          // The sums are over the STORED gradient (rounded to the storage type), as the stand-alone reduce pass reads it.  This pass
+          // is MFMA-bound (the matrix pipe is ~85 % busy at two waves per SIMD), so the arithmetic is packed two channels per
+          // instruction: xhat = fma(y, rstd, -mean rstd); dxhat = g * (xhat > 0 ? 1 : slope); the sums of dxhat, dxhat * xhat and
+          // g * min(xhat, 0).  Columns that are not channels of the norm have g = 0 (zero weight rows, no addend) and rstd = 0.
+          if (ok && ych_ok[j]) {
+            const float* bt = sBt + ((ns * NT + j) * 4 + q4) * 8;
+            const f32x4 rs4 = *reinterpret_cast<const f32x4*>(bt), nm4 = *reinterpret_cast<const f32x4*>(bt + 4);
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+              const uint32_t gw = o2[hlf], yw = yreg[j][i][hlf];
+              const f32x2 g2 = {__uint_as_float(gw << 16), __uint_as_float(gw & 0xffff0000u)};
+              const f32x2 y2 = {__uint_as_float(yw << 16), __uint_as_float(yw & 0xffff0000u)};
+              const f32x2 rs2 = {rs4[2 * hlf], rs4[2 * hlf + 1]}, nm2 = {nm4[2 * hlf], nm4[2 * hlf + 1]};
+              const f32x2 xh = y2 * rs2 + nm2;
+              const f32x2 sel = {xh[0] > 0.f ? 1.f : bal, xh[1] > 0.f ? 1.f : bal};
+              const f32x2 dxh = g2 * sel;
+              const f32x2 neg = {fminf(xh[0], 0.f), fminf(xh[1], 0.f)};
+              f32x2 a1 = {b1[j][2 * hlf], b1[j][2 * hlf + 1]}, a2 = {b2[j][2 * hlf], b2[j][2 * hlf + 1]};
+              a1 += dxh;
+              a2 += dxh * xh;
+              b3[j] = fmaf(g2[0], neg[0], fmaf(g2[1], neg[1], b3[j]));
+              b1[j][2 * hlf] = a1[0]; b1[j][2 * hlf + 1] = a1[1];
+              b2[j][2 * hlf] = a2[0]; b2[j][2 * hlf + 1] = a2[1];
+            }
+          }
+        }
       }
     }
+    if constexpr (BST) { if (y_more) y_load(ynext, i); }
   };
 
   // multiplies of one tile from halo[buf] into `acc`; with PREV the epilogue slices of the previous tile (accumulators `pacc`)
@@ -510,10 +658,10 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
           }
       if constexpr (PREV) {
         constexpr int every = TYPES >= 2 * X_TX ? 2 : 1;          // 9 K-step groups: slices after groups 0,2,4,6; 5 groups: after 0..3
-        if (t % every == 0 && t / every < X_TX) ep_slice(pe, pacc, pcadd, t / every);
+        if (t % every == 0 && t / every < X_TX) ep_slice(pe, pacc, pcadd, t / every, buf ^ 1);
       }
     }
-    if constexpr (ADD == 1) {
+    if constexpr (ADD == 1 && !CADD_LATE) {
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -764,6 +912,11 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
       if ((n < n_first || n > n_last) && tid < E.R) E.part[((int64_t)n * E.P + blockIdx.x) * E.R + tid] = 0.0;
     return;
   }
+  if constexpr (BST) {      // y values of the first tile (every later tile's are fetched by the slices of the tile before it)
+    y_head(ocur, ynext);
+#pragma unroll
+    for (int i = 0; i < X_TX; ++i) y_load(ynext, i);
+  }
   if constexpr (R12) {
     // zero the pad half (channels 12..15) of every plane-1 slot of both buffers once
     for (int i = tid; i < 2 * X_HVP; i += NTHR)
@@ -785,7 +938,7 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
   }
   // invariant at the loop head: set A holds the finished multiplies of tile t (origin ocur); tile t+stride (origin onext) is in
   // flight into halo[1] (R12: already stored there, behind a barrier)
-  constexpr int NSTORE = X_TX * NT;      // vector-memory operations of one tile's epilogue
+  constexpr int NSTORE = X_TX * NT * (BST ? 2 : 1);      // vector-memory operations of one tile's epilogue (BST: a store and a y load per plane)
   auto advance = [&](int buf, f32x4 (&cur)[NT][X_TX], u32x2 (&ccur)[NT][X_TX], f32x4 (&prv)[NT][X_TX], u32x2 (&cprv)[NT][X_TX], bool counted) {
     // tile t+stride becomes the current one: its multiplies go to `cur` while the epilogue of tile t runs from `prv`
     if constexpr (!R12) {
@@ -797,11 +950,12 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
     ocur = onext;
     t += stride;
     const bool more = t + stride < last;
-    if (more) {
-      onext = tile_origin(t + stride);
-      if constexpr (R12) gload(onext); else dma(onext, buf ^ 1);
+    if (more || BST) {
+      onext = tile_origin(more ? t + stride : t);
+      if constexpr (R12) gload(onext, more); else dma(onext, buf ^ 1, more);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (BST) { y_head(ocur, ynext); y_more = true; }
     ep_head(odone, ep);
     compute_tile(T_{}, buf, cur, ccur, ep, prv, cprv);
     if constexpr (R12) {
@@ -811,19 +965,20 @@ __global__ __launch_bounds__(256 * NS) void conv_halo_x_kernel(const ConvKArgs P
   };
   bool counted = false;
   while (true) {
-    if (t + stride >= last) { ep_head(ocur, ep);
+    if (t + stride >= last) { y_more = false; ep_head(ocur, ep);
 #pragma unroll
-      for (int i = 0; i < X_TX; ++i) ep_slice(ep, accA, caddA, i);
+      for (int i = 0; i < X_TX; ++i) ep_slice(ep, accA, caddA, i, 0);
       break; }
     advance(1, accB, caddB, accA, caddA, counted);
     counted = true;
-    if (t + stride >= last) { ep_head(ocur, ep);
+    if (t + stride >= last) { y_more = false; ep_head(ocur, ep);
 #pragma unroll
-      for (int i = 0; i < X_TX; ++i) ep_slice(ep, accB, caddB, i);
+      for (int i = 0; i < X_TX; ++i) ep_slice(ep, accB, caddB, i, 1);
       break; }
     advance(0, accA, caddA, accB, caddB, counted);
   }
   if (STATS && stat_n >= 0) flush_stats(stat_n);
+  if (BST && bst_n >= 0) flush_bst(bst_n);
 }
 
 // -------------------------------------------------------------------------------------------------------------------------------------
@@ -885,17 +1040,48 @@ static int x_grid(const ConvKArgs& a) {
 
 int conv_halo_x_slots(const ConvKArgs& a) { return x_grid(a); }
 
+static int x_add_kind(const ConvKArgs& a);
+// backward statistics: the input-gradient tap order, 16-bit output, any addend but one the epilogue has to load from global memory
+int conv_halo_x_bst_slots(const ConvKArgs& a) {
+  if (x_tap_order(a) != 1 || a.out_f32 || a.stats != nullptr || a.bias != nullptr || x_add_kind(a) == 2) return 0;
+  if (a.bst.col0 != 0 || a.bst.C > a.Cn_store || a.bst.y_ld != a.o_ld) return 0;      // y laid out like the written gradient
+  if (a.Cg * 2 == 64 && a.Cn > 16) return 0;    // (two wave groups at 64-byte voxels: 220-246 registers without the sums; not instantiated)
+  if ((int64_t)a.Xo * a.Yo * a.Zo * a.bst.y_ld * 2 >= (1ll << 31) - 65536) return 0;
+  return x_grid(a);
+}
+
+// how the pass takes its addend: 0 none, 1 centre voxel of the LDS halo, 2 loads in the epilogue, 3 LDS-DMA beside the halo
+static int x_add_kind(const ConvKArgs& a) {
+  if (a.add == nullptr) return 0;
+  const int vb = a.Cg * 2, ncols = a.Cn > 16 ? 32 : 16;      // (the grid has one column of workgroups: they cover every stored channel)
+  const bool stats = a.stats != nullptr, of32 = a.out_f32 != 0;
+  // identity residual: the addend is the input tensor itself, every stored channel is present in the staged voxel
+  const bool addc = a.add == a.in && a.add_ld == a.g_ld && a.add_f32 == 0 && a.Cn_store * 2 <= vb;
+  // a 16-bit addend whose rows hold whole 16-byte chunks goes through the DMA pipeline (64-byte voxels: the LDS has room for it)
+  const bool add_dma = vb == 64 && !of32 && !stats && !addc && a.add_f32 == 0 && (a.add_ld * 2) % 16 == 0 && ((uintptr_t)a.add % 16) == 0 &&
+                       a.add_ld >= ncols && a.g_ld != 12;
+  return addc ? 1 : (add_dma ? 3 : 2);
+}
+
 template <typename H, int VB, int NT, int NS, bool FLIP>
 static void x_launch(ConvKArgs& a, const XGeom& g, int total, dim3 grid, hipStream_t st) {
   const bool stats = a.stats != nullptr, of32 = a.out_f32 != 0;
-  // identity residual: the addend is the input tensor itself, every stored channel is present in the staged voxel
-  const bool addc = a.add == a.in && a.add_ld == a.g_ld && a.add_f32 == 0 && a.Cn_store * 2 <= VB && grid.y == 1;
-  // a 16-bit addend whose rows hold whole 16-byte chunks goes through the DMA pipeline (64-byte voxels: the LDS has room for it)
-  const bool add_dma = VB == 64 && !of32 && !stats && a.add != nullptr && !addc && a.add_f32 == 0 && (a.add_ld * 2) % 16 == 0 && ((uintptr_t)a.add % 16) == 0 &&
-                       a.add_ld >= 16 * NT * NS && a.g_ld != 12;
-  const int add = a.add == nullptr ? 0 : (addc ? 1 : (add_dma ? 3 : 2));
+  const int add = x_add_kind(a);
   const dim3 blk(256 * NS);
   const bool r12 = a.g_ld == 12;
+  if constexpr (FLIP && std::is_same<H, BF16>::value && !(VB == 64 && NS == 2)) {      // input-gradient passes: backward InstanceNorm statistics of the written gradient (training: bf16)
+    if (a.bst.part != nullptr) {
+#define X_BST(AD, R) hipLaunchKernelGGL((conv_halo_x_kernel<H, VB, NT, NS, true, false, AD, false, R, false, true>), grid, blk, 0, st, a, g, total, XCe{})
+      if constexpr (VB == 32 && NS == 1) {
+        if (r12) { if (add == 1) X_BST(1, true); else X_BST(0, true); return; }
+      }
+      if (add == 1) X_BST(1, false);
+      else if (add == 3) { if constexpr (VB == 64) X_BST(3, false); }
+      else X_BST(0, false);
+#undef X_BST
+      return;
+    }
+  }
 #define X_GO(ST, AD, OF)                                                                                                  \
   do {                                                                                                                    \
     if constexpr (VB == 32 && NS == 1) {                                                                                  \
@@ -925,6 +1111,7 @@ void launch_conv_halo_x(ConvKArgs& a, hipStream_t st) {
   g.in_sample_bytes = (int)((int64_t)a.Xi * a.Yi * a.Zi * a.g_ld * 2);
   g.out_sample_bytes = (int)((int64_t)a.Xo * a.Yo * a.Zo * a.o_ld * (a.out_f32 ? 4 : 2));
   g.add_sample_bytes = a.add ? (int)((int64_t)a.Xo * a.Yo * a.Zo * a.add_ld * (a.add_f32 ? 4 : 2)) : 0;
+  g.y_sample_bytes = a.bst.part ? (int)((int64_t)a.Xo * a.Yo * a.Zo * a.bst.y_ld * 2) : 0;
   const int total = g.tiles * a.N;
   const int vb = a.Cg * 2, nt = a.Cn > 16 ? 2 : 1;
   const dim3 grid((unsigned)x_grid(a), 1u, 1u);
@@ -976,6 +1163,7 @@ void launch_conv_halo_x_ce(ConvKArgs& a, const XCe& e, hipStream_t st) {
   g.in_sample_bytes = (int)((int64_t)a.Xi * a.Yi * a.Zi * a.g_ld * 2);
   g.out_sample_bytes = 0;
   g.add_sample_bytes = 0;
+  g.y_sample_bytes = 0;
   const int total = g.tiles * a.N;
   const dim3 grid((unsigned)x_grid_ce(a), 1u, 1u);
   if (a.dtype == CTSEG_F16) x_launch_ce<F16>(a, g, total, grid, e, st); else x_launch_ce<BF16>(a, g, total, grid, e, st);
@@ -995,6 +1183,7 @@ static void x_fill(const ctseg_conv_desc* d, ConvKArgs& a) {
   for (int c = 0; c < CTSEG_MAX_CLASSES; ++c) a.cls[c] = d->cls[c < d->nclass ? c : 0];
   a.out2 = nullptr; a.out2_col0 = 0; a.o2_ld = 0; a.dtype = d->dtype; a.xcd_order = 0;
   a.in_mr = d->in_mean_rstd; a.in_alpha = d->in_alpha; a.in_C = d->in_norm_C;
+  a.bst = BstArgs{};
 }
 
 extern "C" int ctseg_conv_logits_ce_slots(const ctseg_conv_desc* d, int32_t C) {

@@ -294,6 +294,13 @@ static int tile_rows_for(const ConvKArgs& a, int dtype, bool smallc, int nclass)
   return a.Cn <= 32 ? 256 : 128;
 }
 
+// partial rows per sample the pass taking this geometry fills for ConvKArgs::bst (the same kernel selection as the launch); 0: it cannot
+static int bst_slots_for(const ConvKArgs& a, int dtype, int nclass, bool smallc) {
+  if (dtype != CTSEG_BF16 || a.out_f32 || a.bst.C <= 0) return 0;      // (training storage: bf16; fp32 keeps its pinned summation order)
+  if (conv_halo_eligible(a, dtype, nclass)) return conv_halo_x_eligible(a, dtype, nclass) ? conv_halo_x_bst_slots(a) : 0;
+  return 0;
+}
+
 template <typename T> static int launch_dtype(ConvKArgs& a, bool smallc, int nclass, hipStream_t st) {
   const int bm = tile_rows_for(a, TT<T>::DT, smallc, nclass);
   a.tiles = (a.rows + bm - 1) / bm;
@@ -384,6 +391,14 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   a.out2 = (char*)d->out2; a.out2_col0 = d->out2_col0; a.o2_ld = d->o2_ld; a.xcd_order = 0;
   a.dtype = d->dtype;
   a.in_mr = d->in_mean_rstd; a.in_alpha = d->in_alpha; a.in_C = d->in_norm_C;
+  fill_bst(d, a);
+  if (d->bst_partials != nullptr) {
+    const int slots = bst_slots_for(a, d->dtype, d->nclass, smallc);
+    CTSEG_REQUIRE(slots > 0, "conv_igemm: bst_* (backward statistics in the epilogue) is not implemented for this pass (ask ctseg_conv_bwd_stats_slots)");
+    CTSEG_REQUIRE(d->bst_y && d->bst_mean_rstd && d->bst_alpha && d->bst_P >= slots && d->bst_ld >= d->bst_C && d->bst_C > 0 &&
+                      ((uintptr_t)d->bst_y % 8) == 0,
+                  "conv_igemm: bst_* layout (need bst_P >= %d partial rows per sample)", slots);
+  }
   const bool halo = conv_halo_eligible(a, d->dtype, d->nclass);
   if (d->in_mean_rstd != nullptr)
     CTSEG_REQUIRE(halo && conv_halo_x_in_norm_ok(a, d->dtype, d->nclass) && d->in_alpha != nullptr,
@@ -439,6 +454,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
 }
 
 static void fill_args(const ctseg_conv_desc* d, ConvKArgs& a) {
+  fill_bst(d, a);
   a.out2 = nullptr; a.out2_col0 = 0; a.o2_ld = 0; a.xcd_order = 0; a.dtype = d->dtype;
   a.in_mr = d->in_mean_rstd; a.in_alpha = d->in_alpha; a.in_C = d->in_norm_C;
   a.w = (const char*)d->w; a.Cn_store = d->Cn_store;
@@ -461,6 +477,15 @@ extern "C" int ctseg_conv_split_ok(const ctseg_conv_desc* d) {
   if (conv_halo_sw_eligible(a, d->dtype, d->nclass)) return 0;
   if (conv_down_halo_eligible(a, d->dtype, d->nclass)) return 1;
   return (d->out2_col0 % 16 == 0 && conv_down_r_eligible(a, d->dtype, d->nclass)) ? 1 : 0;
+}
+
+extern "C" int ctseg_conv_bwd_stats_slots(const ctseg_conv_desc* d) {
+  if (!desc_ok(d) || !is16(d->dtype) || d->nclass < 1 || d->bst_C <= 0 || d->out_f32) return 0;
+  ConvKArgs a;
+  fill_args(d, a);
+  a.out2 = (char*)d->out2; a.out2_col0 = d->out2_col0; a.o2_ld = d->o2_ld;
+  const bool smallq = (d->Cg % 8) != 0 || (d->g_ld % 8) != 0 || ((uintptr_t)d->in % 16) != 0;
+  return bst_slots_for(a, d->dtype, d->nclass, smallq);
 }
 
 extern "C" int ctseg_conv_in_norm_ok(const ctseg_conv_desc* d) {

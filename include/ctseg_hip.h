@@ -25,8 +25,10 @@ extern "C" {
 
 /* ABI history.  1: round 1.  2: both descriptor structs start with `struct_size` (= sizeof of the struct the CALLER was compiled
  * against); every entry point that takes a descriptor rejects a size it does not know, so a caller built against an older header
- * can never make the library read past the end of its struct (round 2 appended fields to both structs under version 1). */
-#define CTSEG_ABI_VERSION 2
+ * can never make the library read past the end of its struct (round 2 appended fields to both structs under version 1).
+ * 3: ctseg_conv_desc ends with the bst_* fields (backward InstanceNorm statistics taken in the epilogue of the pass that writes
+ * the gradient); ctseg_conv_bwd_stats_slots(). */
+#define CTSEG_ABI_VERSION 3
 #define CTSEG_F32 0
 #define CTSEG_BF16 1
 #define CTSEG_I16 2 /* raw-input dtypes of ctseg_resize3d_to_hwd only */
@@ -89,6 +91,24 @@ typedef struct ctseg_conv_desc {
   const float* in_mean_rstd;
   const float* in_alpha;
   int32_t in_norm_C;
+  /* Optional backward statistics of the InstanceNorm + PReLU whose OUTPUT GRADIENT this pass writes (where
+   * ctseg_conv_bwd_stats_slots() > 0).  The written tensor is g = dL/d prelu(xhat), xhat = (y - mean) * rstd with y the forward
+   * convolution output that norm normalised (autograd of monai Convolution's ADN, reached through loss.backward() at reference
+   * capstone/volumetric/base_trainer.py:80-82).  Its backward needs, per (sample, channel), sum dxhat, sum dxhat * xhat
+   * (dxhat = g * prelu'(xhat)) and sum g * min(xhat, 0) (the slope gradient) — what ctseg_instnorm_prelu_bwd_reduce computes in a
+   * pass of its own over (g, y).  With bst_partials set, the epilogue of THIS pass reads the matching y tile and accumulates the
+   * three sums of the values it stores (after the addend, rounded to the storage type), one partial row per workgroup (or tile)
+   * and sample: bst_partials[n][p][3][bst_ld], p < bst_P — exactly ctseg_instnorm_prelu_bwd_finalize's input, so the reduce
+   * pass and its second read of g disappear.  Columns [bst_col0, bst_col0 + bst_C) of the pass carry channels 0..bst_C-1 of the
+   * norm (bst_col0 != 0: the norm sits behind the second half of a split output, bst_col0 == out2_col0).  bst_y is indexed like
+   * the written tensor (same voxels), channel stride bst_y_ld, storage dtype of the pass.  The caller zero-fills bst_partials
+   * once: a workgroup only writes the rows of samples it worked on.  bst_partials == NULL: feature off. */
+  const void* bst_y;
+  const float* bst_mean_rstd;  /* [N][bst_C][2] as ctseg_instnorm_finalize writes it */
+  const float* bst_alpha;      /* the PReLU slope (one value)                        */
+  float* bst_partials;
+  int32_t bst_y_ld, bst_C, bst_col0, bst_P, bst_ld;
+  int32_t reserved1;
 } ctseg_conv_desc;
 
 /* Rows of the row grid / output columns one workgroup tile covers for a pass with Cn columns. */
@@ -108,6 +128,10 @@ int ctseg_conv_narrow_ok(const ctseg_conv_desc* d);
 /* 1 if a pass with this geometry can take in_mean_rstd / in_alpha / in_norm_C (pointers are ignored): the x-column LDS-halo pass
  * over 12-wide 16-bit rows (whose operand is staged through registers), at most 16 samples and 12 normalised channels */
 int ctseg_conv_in_norm_ok(const ctseg_conv_desc* d);
+/* Partial rows per sample (bst_P) the pass with this geometry fills when bst_partials is set; 0: the pass cannot take the bst_*
+ * fields (run ctseg_instnorm_prelu_bwd_reduce instead).  bst_y_ld, bst_C, bst_col0 must be set; pointers other than in / out /
+ * out2 / add (which select the kernel) are ignored. */
+int ctseg_conv_bwd_stats_slots(const ctseg_conv_desc* d);
 int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream);
 
 /* Weight gradient: R[tap*Cg+a][b] = sum_rows in[row*sin+d(tap)][a] * dy[row][b]; row K=ntaps*Cg of R is

@@ -99,6 +99,25 @@ class Emulator:
                 out_b[sl] = full[..., c0:]
             else:
                 out[sl] = full
+        if d.bst_partials:
+            # backward InstanceNorm statistics of the written gradient (ctseg_conv_desc::bst_*): the three sums of
+            # instnorm_prelu_bwd_reduce over the values this pass stored, in partial row 0 of every sample
+            C, c0 = d.bst_C, d.bst_col0
+            if d.out2:
+                assert c0 == d.out2_col0
+                g = cl_view(d.out2, N, d.Xo, d.Yo, d.Zo, C, d.o2_ld)
+            else:
+                g = cl_view(d.out, N, d.Xo, d.Yo, d.Zo, cs, d.o_ld)[..., c0:c0 + C]
+            yv = cl_view(d.bst_y, N, d.Xo, d.Yo, d.Zo, C, d.bst_y_ld)
+            mr = mem(d.bst_mean_rstd, N * C * 2).reshape(N, 1, 1, 1, C, 2)
+            a = mem(d.bst_alpha, 1)[0]
+            xh = (yv - mr[..., 0]) * mr[..., 1]
+            dxh = g * np.where(xh > 0, 1.0, a).astype(np.float32)
+            p = mem(d.bst_partials, N * d.bst_P * 3 * d.bst_ld).reshape(N, d.bst_P, 3, d.bst_ld)
+            p[:] = 0
+            p[:, 0, 0, :C] = dxh.sum(axis=(1, 2, 3))
+            p[:, 0, 1, :C] = (dxh * xh).sum(axis=(1, 2, 3))
+            p[:, 0, 2, :C] = np.where(xh > 0, 0, g * xh).sum(axis=(1, 2, 3))
 
     def conv_wgrad(self, d):
         assert d.dtype == F32
@@ -395,7 +414,8 @@ def patch_native(nat, emu):
     orig_req = nat.require_gpu
     nat.require_gpu = lambda t, what: None
     orig_query = nat.query
-    own = {"ctseg_conv_split_ok": emu.conv_split_ok, "ctseg_conv_narrow_ok": lambda d: 0, "ctseg_wgrad_narrow_ok": lambda d: 0}
+    own = {"ctseg_conv_split_ok": emu.conv_split_ok, "ctseg_conv_narrow_ok": lambda d: 0, "ctseg_wgrad_narrow_ok": lambda d: 0,
+           "ctseg_conv_bwd_stats_slots": lambda d: 1}
     nat.query = lambda name, d: own[name](d) if name in own else orig_query(name, d)
 
     def undo():

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported_and_bound():
 def test_host_side_queries_and_validation():
     L = nat.lib()
     hdr = int(re.search(r"#define CTSEG_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
-    assert L.ctseg_abi_version() == hdr == nat.ABI_VERSION == 2
+    assert L.ctseg_abi_version() == hdr == nat.ABI_VERSION == 3
     assert (L.ctseg_conv_tile_rows(10), L.ctseg_conv_tile_rows(256)) == (256, 128)
     assert [L.ctseg_conv_tile_cols(c) for c in (10, 32, 64, 256)] == [16, 32, 64, 128]
     assert [L.ctseg_wgrad_tile_cols(c) for c in (10, 32, 64, 256)] == [16, 32, 64, 128]

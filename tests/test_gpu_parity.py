@@ -35,7 +35,7 @@ def _mods():
 
 def test_native_library_is_the_in_tree_build():
     L = nat.lib()
-    assert L.ctseg_abi_version() == nat.ABI_VERSION == 2
+    assert L.ctseg_abi_version() == nat.ABI_VERSION == 3
     assert os.path.realpath(nat.LIB_PATH).startswith(os.path.realpath(os.path.join(os.path.dirname(__file__), "..")))
     assert any("libctseg_hip.so" in line for line in open("/proc/self/maps"))
 
