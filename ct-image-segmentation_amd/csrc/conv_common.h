@@ -22,6 +22,19 @@ __device__ __forceinline__ void bst_term(float g, float yv, float mean, float rs
   a3 += xh > 0.f ? 0.f : g * xh;
 }
 
+// the same three sums for two channels held as a packed bf16 pair (low half = first channel): full-rate packed fp32 arithmetic,
+// xhat = fma(y, rstd, -mean * rstd).  a3 is ONE accumulator (the slope is one parameter: only the total over channels matters).
+__device__ __forceinline__ void bst_pair_bf16(uint32_t gw, uint32_t yw, f32x2 rstd, f32x2 nmr, float al, f32x2& a1, f32x2& a2, float& a3) {
+  const f32x2 g2 = {__uint_as_float(gw << 16), __uint_as_float(gw & 0xffff0000u)};
+  const f32x2 y2 = {__uint_as_float(yw << 16), __uint_as_float(yw & 0xffff0000u)};
+  const f32x2 xh = y2 * rstd + nmr;
+  const f32x2 sel = {xh[0] > 0.f ? 1.f : al, xh[1] > 0.f ? 1.f : al};
+  const f32x2 dxh = g2 * sel;
+  a1 += dxh;
+  a2 += dxh * xh;
+  a3 = fmaf(g2[0], fminf(xh[0], 0.f), fmaf(g2[1], fminf(xh[1], 0.f), a3));
+}
+
 struct ConvKArgs {
   const char* in;
   const char* w;
@@ -146,6 +159,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
     const int64_t slot_t = (int64_t)n * P.stats_tiles + P.stats_tile0 + (int64_t)cls_index * P.tiles + tile;
     P.stats[(slot_t * 2 + which) * P.stats_ld + col0 + c] = a;
   }
+  // backward InstanceNorm statistics of the stored gradient (ConvKArgs::bst): a thread keeps ONE 8-channel chunk column through the
+  // store loop below (NTHR is a multiple of the chunks per row), so its 8 + 8 + 1 sums stay in registers for the whole tile
+  const bool bst = SZ == 2 && !of32 && P.bst.part != nullptr;
+  f32x2 q_rs[4], q_nm[4], q1[4], q2[4];
+  float q3 = 0.f, q_al = 1.f;
+  int q_ch0 = 0;                                  // channel of the norm the thread's chunk starts at (may be < 0 or >= C: not a channel)
+  if (bst) {
+    q_al = P.bst.alpha[0];
+    q_ch0 = col0 + (tid % (BN / 8)) * 8 - P.bst.col0;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      q1[h] = f32x2{0.f, 0.f}; q2[h] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = q_ch0 + 2 * h + e;
+        const bool okc = c >= 0 && c < P.bst.C;
+        const float mean = okc ? P.bst.mr[((int64_t)n * P.bst.C + c) * 2] : 0.f, rstd = okc ? P.bst.mr[((int64_t)n * P.bst.C + c) * 2 + 1] : 0.f;
+        q_rs[h][e] = rstd;
+        q_nm[h][e] = -mean * rstd;
+      }
+    }
+  }
   {
     const int EPO = 16 / OSZ;               // output elements per 16-byte chunk
     const int cpr = BN / EPO;                // chunks per tile row
@@ -158,7 +193,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
     for (int base = tid; base < BM * cpr; base += NTHR * UN) {
       char* op[UN];
       const char* cp[UN];
-      u32x4 a0[UN], a1[UN];
+      u32x4 a0[UN], a1[UN], yq[UN];
       bool ok[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
@@ -174,6 +209,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
         op[u] = P.out + (vox * P.o_ld + ch) * OSZ;
         a0[u] = u32x4{0u, 0u, 0u, 0u};
         a1[u] = a0[u];
+        yq[u] = a0[u];
+        if (bst && ok[u] && q_ch0 >= 0 && q_ch0 < P.bst.C)
+          yq[u] = *reinterpret_cast<const u32x4*>(P.bst.y + (vox * P.bst.y_ld + q_ch0) * 2);
         if (ok[u] && P.add != nullptr) {
           const char* ap = P.add + (vox * P.add_ld + ch) * ASZ;
           if (nadd == 8) { const u32x2 t = *reinterpret_cast<const u32x2*>(ap); a0[u][0] = t[0]; a0[u][1] = t[1]; }
@@ -187,7 +225,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
       for (int u = 0; u < UN; ++u) {
         if (!ok[u]) continue;
         if (P.add == nullptr) {
-          *reinterpret_cast<u32x4*>(op[u]) = *reinterpret_cast<const u32x4*>(cp[u]);
+          const u32x4 t = *reinterpret_cast<const u32x4*>(cp[u]);
+          *reinterpret_cast<u32x4*>(op[u]) = t;
+          if (bst) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) bst_pair_bf16(t[h], yq[u][h], q_rs[h], q_nm[h], q_al, q1[h], q2[h], q3);
+          }
+        } else if (bst) {       // (16-bit output: the sums are over the values as stored)
+          float v[8], a[8];
+          load_n_as_float<H>(cp[u], false, 8, v);
+          if (af32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = __uint_as_float(a0[u][e]); a[4 + e] = __uint_as_float(a1[u][e]); }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[2 * e] = h2f<H>(a0[u][e] & 0xffffu); a[2 * e + 1] = h2f<H>(a0[u][e] >> 16); }
+          }
+          u32x4 t;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) t[h] = pack2<H>(v[2 * h] + a[2 * h], v[2 * h + 1] + a[2 * h + 1]);
+          *reinterpret_cast<u32x4*>(op[u]) = t;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) bst_pair_bf16(t[h], yq[u][h], q_rs[h], q_nm[h], q_al, q1[h], q2[h], q3);
         } else {
           float v[8], a[8];
           load_n_as_float<H>(cp[u], of32 || SZ == 4, EPO, v);
@@ -203,6 +262,36 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
           else store_chunk<H>(op[u], v);
         }
       }
+    }
+  }
+  if (bst) {
+    // lanes l, l + cpr, l + 2 cpr ... of a wave hold the same chunk column (cpr = BN / 8 divides 64): butterflies, then the waves
+    // in order through LDS (the transposed tile is dead once every thread has left the store loop) — fixed order, no atomics
+    constexpr int CPR = BN / 8, NW = WGM * WGN;
+    float qv[17];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { qv[2 * h] = q1[h][0]; qv[2 * h + 1] = q1[h][1]; qv[8 + 2 * h] = q2[h][0]; qv[9 + 2 * h] = q2[h][1]; }
+    qv[16] = q3;
+#pragma unroll
+    for (int k = 0; k < 17; ++k)
+#pragma unroll
+      for (int o = 32; o >= CPR; o >>= 1) qv[k] += __shfl_xor(qv[k], o, 64);
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane < CPR) {
+#pragma unroll
+      for (int k = 0; k < 17; ++k) red[(wave * CPR + lane) * 17 + k] = qv[k];
+    }
+    __syncthreads();
+    for (int i = tid; i < 17 * CPR; i += NTHR) {
+      const int cc = i / 17, k = i - cc * 17;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[(w * CPR + cc) * 17 + k];
+      const int which = k < 8 ? 0 : (k < 16 ? 1 : 2);
+      const int c = col0 + cc * 8 + (k & 7) * (k < 16 ? 1 : 0) - P.bst.col0;
+      const int64_t slot = (int64_t)n * P.bst.P + (int64_t)cls_index * P.tiles + tile;
+      if (c >= 0 && c < P.bst.C) P.bst.part[(slot * 3 + which) * P.bst.ld + c] = s;
     }
   }
 }

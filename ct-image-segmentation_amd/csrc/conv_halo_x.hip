@@ -114,7 +114,13 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
   // WL: the packed weights live in LDS in FRAGMENT order (1 KB per (column block, dx, K-step group): lane l reads its 16 bytes at
   // l * 16, conflict free by construction) instead of in registers: 54 fragments = 216 registers per lane do not fit beside the
   // operand prefetch (MFMA A/B operands come from the 256 architectural VGPRs)
-  constexpr bool WL = false;     // weights in registers (see above: the same speed, and the LDS goes to the addend staging of ADD == 3)
+  // Weights in registers (see above: the same speed, and the LDS goes to the addend staging of ADD == 3) — except with BST at
+  // 64-byte voxels and two wave groups: that variant needs 220-246 registers without the three sums, their constants and the y
+  // values, so its 54 weight fragments live in LDS.  A1: its DMA-staged addend then has ONE buffer, laid out per wave (a wave
+  // stages exactly the 64 voxels x 2 chunks it reads itself), read into registers before the wave issues the next tile's pieces.
+  constexpr bool WL = BST && VB == 64 && NS == 2;
+  constexpr bool A1 = WL && ADD == 3;
+  constexpr int NAB = A1 ? 1 : 2;
   constexpr int NTA = NT * NS;                           // column blocks of the workgroup
   constexpr int WBYTES = WL ? NTA * 3 * CF::TYPES * 1024 : 0;
   constexpr int NPL = CF::NPL, TYPES = CF::TYPES, NW = 4 * NS, NTHR = 64 * NW;
@@ -134,11 +140,11 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
   constexpr int CE_L = CE ? NW * 3 * 6 * 64 * 4 : 0;         // per-LANE Dice counters: [wave][kind][class pair][lane], two 16-bit fields per word
   constexpr int ST_B = NW * (BST ? 3 : 2) * 16 * NT * 4;     // per-wave statistics slots (forward: sum, sum of squares; BST: three sums)
   constexpr int BT_B = BST ? 16 * NTA * 2 * 4 : 0;           // BST: (mean x 4, rstd x 4) per channel quad of the current sample
-  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + 2 * ABUF + NRM_B + CE_L + BT_B];
-  float* const sBt = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + 2 * ABUF + NRM_B + CE_L);
-  char* const sLaneBase = smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + 2 * ABUF + NRM_B;
+  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + NAB * ABUF + NRM_B + CE_L + BT_B];
+  float* const sBt = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + NAB * ABUF + NRM_B + CE_L);
+  char* const sLaneBase = smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + NAB * ABUF + NRM_B;
   char* const sA = smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B;
-  float* const sPar = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + 2 * ABUF);
+  float* const sPar = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + NAB * ABUF);
   char* const sW = smem + 2 * CF::HALO;
   float* const sStats = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES);     // per-wave statistics slots
   char* const sT = smem + 2 * CF::HALO + WBYTES + ST_B;
@@ -219,6 +225,17 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
   if constexpr (ADD == 3) {
 #pragma unroll
     for (int j = 0; j < APW; ++j) {
+      if constexpr (A1) {
+        // piece j of this wave: lane (x plane l >> 4, patch voxel l & 15 of the wave's y pair), chunk 2 ns + j — what the wave's own
+        // lanes read back (lane (r16, q4): plane i, chunk 2 ns + (q4 >> 1) at lane slot i * 16 + r16 of piece q4 >> 1)
+        static_assert(!A1 || APW == 2, "two chunks per wave group");
+        int ady, az;
+        x_patch_voxel(lane & 15, ady, az);
+        const int ix = lane >> 4, iy = 2 * yp + ady, iz = az;
+        apoff[j] = ((ix * P.Yo + iy) * P.Zo + iz) * P.add_ld * 2 + (blockIdx.y * ACH + 2 * ns + j) * 16;
+        aphot[j] = (1u << ix) | (1u << (4 + iy)) | (1u << (12 + iz));
+        continue;
+      }
       const int ci = (wave + j * NW) * 64 + lane, tv = ci / ACH, ch = ci - tv * ACH;
       const int ix = tv >> 6, iy = (tv >> 3) & 7, iz = tv & 7;
       // 64-byte voxels (ACH = 4): the 16-byte chunk at LDS position ch holds channel chunk ch ^ ((voxel >> 2) & 3) — the 16 voxels x
@@ -309,7 +326,6 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
   // ---- BST: per-lane sums of the lane's 4 channels (x NT column blocks), constants of the current sample -----------------------
   // (the third sum feeds the gradient of the ONE PReLU slope: only its total over channels matters, so a lane keeps one accumulator
   // for its four channels and reports it under the first of them)
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
   float b1[NT][4], b2[NT][4], b3[NT];
   u32x2 yreg[NT][X_TX];
 #pragma unroll
@@ -408,7 +424,8 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
 #pragma unroll
       for (int j = 0; j < APW; ++j) {
         const int vo = (live && (aphot[j] & anot) == 0u) ? apoff[j] : (int)0x80000000;
-        x_raw_buffer_load_lds(ars, (x_lds_u32_ptr)(sA + buf * ABUF + (wave + j * NW) * 1024), 16, vo, asoff, 0, 0);
+        if constexpr (A1) x_raw_buffer_load_lds(ars, (x_lds_u32_ptr)(sA + (wave * APW + j) * 1024), 16, vo, asoff, 0, 0);
+        else x_raw_buffer_load_lds(ars, (x_lds_u32_ptr)(sA + buf * ABUF + (wave + j * NW) * 1024), 16, vo, asoff, 0, 0);
       }
     }
   };
@@ -611,6 +628,18 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
     if constexpr (BST) { if (y_more) y_load(ynext, i); }
   };
 
+  // A1: the addend of the tile about to be multiplied, out of the wave's own part of the single addend buffer — complete before
+  // the wave issues the pieces of the tile after it into the same slots
+  auto cadd_early = [&](u32x2 (&cadd)[NT][X_TX]) {
+    if constexpr (A1) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < X_TX; ++i)
+          cadd[j][i] = *reinterpret_cast<const u32x2*>(sA + ((wave * 2 + (q4 >> 1)) * 64 + i * 16 + r16) * 16 + (q4 & 1) * 8);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
   // multiplies of one tile from halo[buf] into `acc`; with PREV the epilogue slices of the previous tile (accumulators `pacc`)
   // are spread over the K steps: their conversions, statistics and stores issue under this tile's MFMAs
   auto compute_tile = [&](auto prev_c, int buf, f32x4 (&acc)[NT][X_TX], u32x2 (&cadd)[NT][X_TX], const Ep& pe,
@@ -666,7 +695,7 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < X_TX; ++i) cadd[j][i] = *reinterpret_cast<const u32x2*>(hb + cbase + 2 * j * X_PLANE + i * X_XSTRIDE);
-    } else if constexpr (ADD == 3) {
+    } else if constexpr (ADD == 3 && !A1) {
       const int av = (2 * yp + pdy) * 8 + pz, asw = ACH == 4 ? ((av >> 2) & 3) : 0;       // (the swizzle of the DMA source side)
       const char* ab = sA + buf * ABUF + av * ACH * 16 + (q4 & 1) * 8;
 #pragma unroll
@@ -933,6 +962,7 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
     dma(ocur, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // DMA pieces landed; the weight fragments this wave staged are written
     __builtin_amdgcn_s_barrier();
+    cadd_early(caddA);
     if (t + stride < last) { onext = tile_origin(t + stride); dma(onext, 1); }
     compute_tile(F_{}, 0, accA, caddA, ep, accA, caddA);
   }
@@ -950,6 +980,7 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
     ocur = onext;
     t += stride;
     const bool more = t + stride < last;
+    cadd_early(ccur);
     if (more || BST) {
       onext = tile_origin(more ? t + stride : t);
       if constexpr (R12) gload(onext, more); else dma(onext, buf ^ 1, more);
@@ -1045,7 +1076,7 @@ static int x_add_kind(const ConvKArgs& a);
 int conv_halo_x_bst_slots(const ConvKArgs& a) {
   if (x_tap_order(a) != 1 || a.out_f32 || a.stats != nullptr || a.bias != nullptr || x_add_kind(a) == 2) return 0;
   if (a.bst.col0 != 0 || a.bst.C > a.Cn_store || a.bst.y_ld != a.o_ld) return 0;      // y laid out like the written gradient
-  if (a.Cg * 2 == 64 && a.Cn > 16) return 0;    // (two wave groups at 64-byte voxels: 220-246 registers without the sums; not instantiated)
+  { const char* e = getenv("CTSEG_BST_X64"); if (a.Cg * 2 == 64 && a.Cn > 16 && e != nullptr && e[0] == '0') return 0; }   // (A/B switch)
   if ((int64_t)a.Xo * a.Yo * a.Zo * a.bst.y_ld * 2 >= (1ll << 31) - 65536) return 0;
   return x_grid(a);
 }
@@ -1069,7 +1100,7 @@ static void x_launch(ConvKArgs& a, const XGeom& g, int total, dim3 grid, hipStre
   const int add = x_add_kind(a);
   const dim3 blk(256 * NS);
   const bool r12 = a.g_ld == 12;
-  if constexpr (FLIP && std::is_same<H, BF16>::value && !(VB == 64 && NS == 2)) {      // input-gradient passes: backward InstanceNorm statistics of the written gradient (training: bf16)
+  if constexpr (FLIP && std::is_same<H, BF16>::value) {      // input-gradient passes: backward InstanceNorm statistics of the written gradient (training: bf16)
     if (a.bst.part != nullptr) {
 #define X_BST(AD, R) hipLaunchKernelGGL((conv_halo_x_kernel<H, VB, NT, NS, true, false, AD, false, R, false, true>), grid, blk, 0, st, a, g, total, XCe{})
       if constexpr (VB == 32 && NS == 1) {

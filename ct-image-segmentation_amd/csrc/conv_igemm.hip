@@ -298,7 +298,17 @@ static int tile_rows_for(const ConvKArgs& a, int dtype, bool smallc, int nclass)
 static int bst_slots_for(const ConvKArgs& a, int dtype, int nclass, bool smallc) {
   if (dtype != CTSEG_BF16 || a.out_f32 || a.bst.C <= 0) return 0;      // (training storage: bf16; fp32 keeps its pinned summation order)
   if (conv_halo_eligible(a, dtype, nclass)) return conv_halo_x_eligible(a, dtype, nclass) ? conv_halo_x_bst_slots(a) : 0;
-  return 0;
+  if (conv_up_eligible(a, dtype, nclass) || conv_stem_eligible(a, dtype, nclass)) return 0;
+  if (conv_halo_sw_eligible(a, dtype, nclass)) return 0;
+  if (conv_down_halo_eligible(a, dtype, nclass)) return 0;
+  if (conv_down_r_eligible(a, dtype, nclass)) return 0;
+  { const char* e = getenv("CTSEG_BST_GENERIC"); if (e != nullptr && e[0] == '0') return 0; }   // (A/B switch)
+  // generic / ring kernels (conv_epilogue): one partial row per (class, tile); whole 16-byte chunks of y beside those of the output
+  if (smallc || a.out2 != nullptr || a.o_ld % 8 != 0 || a.Cn_store % 8 != 0 || a.bst.col0 % 8 != 0 || a.bst.y_ld % 8 != 0 ||
+      ((uintptr_t)a.bst.y % 16) != 0 || a.bst.col0 + a.bst.C > a.Cn_store)
+    return 0;
+  const int bm = tile_rows_for(a, dtype, smallc, nclass);
+  return ((a.rows + bm - 1) / bm) * nclass;
 }
 
 template <typename T> static int launch_dtype(ConvKArgs& a, bool smallc, int nclass, hipStream_t st) {

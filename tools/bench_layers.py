@@ -36,7 +36,7 @@ def describe(name, args, dt):
             # an addend is a SECOND read stream only when it is another tensor, and then in ITS storage type (fp32 logits take a
             # 16-bit addend); an identity residual (add == in) is served from the staged operand: 0 algorithmic bytes
             byt += d.N * d.Xo * d.Yo * d.Zo * d.Cn_store * (4 if d.add_f32 else sz)
-        return f"conv Cg={d.Cg:3d} Cn={d.Cn:3d} in={d.Xi}x{d.Yi}x{d.Zi} rows={d.Xr}x{d.Yr}x{d.Zr} cls={d.nclass} s={d.sin}/{d.sout}" \
+        return f"conv Cg={d.Cg:3d} Cn={d.Cn:3d} in={d.Xi}x{d.Yi}x{d.Zi} rows={d.Xr}x{d.Yr}x{d.Zr} cls={d.nclass} s={d.sin}/{d.sout}{' +bst' if d.bst_partials else ''}" \
                f"{' +add' if d.add else ''}{' +stats' if d.stats else ''}{' f32out' if d.out_f32 else ''}", flop, byt
     if name == "ctseg_conv_wgrad":
         d = args[0]
