@@ -10,7 +10,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libctseg_hip.so")
+# CTSEG_LIB: another build of the same library (tests/test_host_sanitizer.py loads the host-sanitizer build on the CPU); default and
+# product path: the in-tree build
+LIB_PATH = os.environ.get("CTSEG_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libctseg_hip.so")
 
 F32, BF16, I16, U8, F16 = 0, 1, 2, 3, 4      # F16: IEEE half storage, forward (inference) passes only
 MAX_TAPS, MAX_CLASSES = 27, 8

@@ -490,7 +490,7 @@ extern "C" int ctseg_conv_split_ok(const ctseg_conv_desc* d) {
 }
 
 extern "C" int ctseg_conv_bwd_stats_slots(const ctseg_conv_desc* d) {
-  if (!desc_ok(d) || !is16(d->dtype) || d->nclass < 1 || d->bst_C <= 0 || d->out_f32) return 0;
+  if (!desc_ok(d) || !is16(d->dtype) || d->nclass < 1 || d->nclass > CTSEG_MAX_CLASSES || d->bst_C <= 0 || d->out_f32) return 0;
   ConvKArgs a;
   fill_args(d, a);
   a.out2 = (char*)d->out2; a.out2_col0 = d->out2_col0; a.o2_ld = d->o2_ld;
@@ -499,7 +499,7 @@ extern "C" int ctseg_conv_bwd_stats_slots(const ctseg_conv_desc* d) {
 }
 
 extern "C" int ctseg_conv_in_norm_ok(const ctseg_conv_desc* d) {
-  if (!desc_ok(d) || !is16(d->dtype) || d->nclass < 1) return 0;
+  if (!desc_ok(d) || !is16(d->dtype) || d->nclass < 1 || d->nclass > CTSEG_MAX_CLASSES) return 0;
   ConvKArgs a;
   fill_args(d, a);
   return (conv_halo_eligible(a, d->dtype, d->nclass) && conv_halo_x_in_norm_ok(a, d->dtype, d->nclass)) ? 1 : 0;
@@ -509,7 +509,7 @@ extern "C" int ctseg_conv_in_norm_ok(const ctseg_conv_desc* d) {
 // the resident-weight LDS-halo kernel (any of them narrow), by the stride-2 "up" kernel (narrow output / addend only) or by the
 // stride-2 "down" halo kernel (narrow gathered operand only)
 extern "C" int ctseg_conv_narrow_ok(const ctseg_conv_desc* d) {
-  if (!desc_ok(d) || !is16(d->dtype) || d->nclass < 1) return 0;
+  if (!desc_ok(d) || !is16(d->dtype) || d->nclass < 1 || d->nclass > CTSEG_MAX_CLASSES) return 0;
   ConvKArgs a;
   fill_args(d, a);
   a.out_f32 = d->out_f32; a.Xo = d->Xo; a.Yo = d->Yo; a.Zo = d->Zo; a.add = (const char*)d->add; a.o_ld = d->o_ld;
@@ -524,7 +524,7 @@ extern "C" int ctseg_conv_narrow_ok(const ctseg_conv_desc* d) {
 
 // tiles per sample (all classes) a pass with this geometry writes InstanceNorm partials for
 extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
-  if (!desc_ok(d) || d->nclass < 1) return -1;
+  if (!desc_ok(d) || d->nclass < 1 || d->nclass > CTSEG_MAX_CLASSES) return -1;
   ConvKArgs a;
   fill_args(d, a);
   if (conv_halo_eligible(a, d->dtype, d->nclass)) return conv_halo_slots(a, d->dtype);
