@@ -122,7 +122,7 @@ _SIGS = {
     "ctseg_dice_counts": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     "ctseg_reduce_partials_f64": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "ctseg_loss_dice_summary": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
-    "ctseg_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "ctseg_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _i32, _f32, _vp]),
     "ctseg_scale_inplace": (C.c_int, [_vp, _i32, _i64, _vp, _f32, _vp]),
     "ctseg_cast": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp]),
     "ctseg_nc_to_cl": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),

@@ -88,7 +88,9 @@ class _NormAct:
         a_ptr = plan.store.p_ptr(self.alpha)
         mark = getattr(g, "bst", None)
         fused = mark is not None and mark[0] is self
-        plan.norm_bwd.append((sums, fused))        # (tests: the statistics of every norm's backward, and where they came from)
+        rec = getattr(plan, "norm_bwd", None)      # (tests: the statistics of every norm's backward, and where they came from)
+        if rec is not None:
+            rec.append((sums, fused))
         if fused:
             # the pass that wrote g took the three sums in its epilogue (ctseg_conv_desc::bst_*): no reduce pass, no second read of g
             _, part, P, ld = mark

@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
   constexpr int CE_L = CE ? NW * 3 * 6 * 64 * 4 : 0;         // per-LANE Dice counters: [wave][kind][class pair][lane], two 16-bit fields per word
   constexpr int ST_B = NW * (BST ? 3 : 2) * 16 * NT * 4;     // per-wave statistics slots (forward: sum, sum of squares; BST: three sums)
   constexpr int BT_B = BST ? 16 * NTA * 2 * 4 : 0;           // BST: (mean x 4, rstd x 4) per channel quad of the current sample
-  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + NAB * ABUF + NRM_B + CE_L + BT_B];
+  constexpr int CAD_B = (BST && R12 && ADD == 1 && !CE) ? 2 * NT * X_TX * 256 * NS * 8 : 0;   // lane-private centre voxels of two tiles
+  __shared__ __attribute__((aligned(16))) char smem[2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + NAB * ABUF + NRM_B + CE_L + BT_B + CAD_B];
+  char* const sCad = smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + NAB * ABUF + NRM_B + CE_L + BT_B;
   float* const sBt = reinterpret_cast<float*>(smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + NAB * ABUF + NRM_B + CE_L);
   char* const sLaneBase = smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B + NAB * ABUF + NRM_B;
   char* const sA = smem + 2 * CF::HALO + WBYTES + ST_B + CE_T + CE_B;
@@ -288,7 +290,10 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bias[j][e] = (!BST && P.bias != nullptr && chn + 16 * j + e < P.Cn) ? P.bias[chn + 16 * j + e] : 0.f;   // (BST: a gradient pass, no bias: host-checked)
+    for (int e = 0; e < 4; ++e) {
+      bias[j][e] = (!BST && P.bias != nullptr && chn + 16 * j + e < P.Cn) ? P.bias[chn + 16 * j + e] : 0.f;   // (BST: a gradient pass, no bias: host-checked)
+      if (CE && chn + 16 * j + e >= E.C) bias[j][e] = -3.0e38f;       // fused cross-entropy: a column that is not a class never wins the maximum, e = 0
+    }
 
   float wsum[NT][4], wsq[NT][4];
 #pragma unroll
@@ -550,16 +555,18 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
   };
   Yl ynext;
   bool y_more = false;          // workgroup-uniform: the slices fetch the y values of the tile being multiplied
-  // R12 && ADD == 1: the halo of the tile whose epilogue runs is still intact while the next tile multiplies (the register-staged
-  // pipeline stores the tile after next only behind those multiplies), so a slice reads its identity-residual addend from there
-  // instead of carrying 2 x 8 registers of centre voxels through the multiplies
-  constexpr bool CADD_LATE = R12 && ADD == 1 && !CE;
+  // BST && R12 && ADD == 1 (the head's input gradient, at the 256-register line of two waves per SIMD): the identity-residual
+  // addend of a tile (the centre voxels of its halo) does not ride through the next tile's multiplies in 2 x 8 registers but in a
+  // lane-private LDS slot, written when the tile's multiplies end and read back by the slices.  (Reading the halo itself from the
+  // slices RACED: a wave that finishes its multiplies early stores the tile after next over it while a slower wave's slices still
+  // read — 2 % of the logits off at 2 x 512 x 512 x 48, nothing at the small test shapes.)
+  constexpr bool CADD_LATE = BST && R12 && ADD == 1 && !CE;
   auto ep_slice = [&](const Ep& e, const f32x4 (&acc)[NT][X_TX], const u32x2 (&cadd_)[NT][X_TX], int i, int hbuf) {
     const bool ok = e.lane_ok && i < e.nx;
     u32x2 cadd[NT][X_TX];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      if constexpr (CADD_LATE) cadd[j][i] = *reinterpret_cast<const u32x2*>(smem + hbuf * CF::HALO + cbase + 2 * j * X_PLANE + i * X_XSTRIDE);
+      if constexpr (CADD_LATE) cadd[j][i] = *reinterpret_cast<const u32x2*>(sCad + (((hbuf * NT + j) * X_TX + i) * NTHR + tid) * 8);
       else cadd[j][i] = cadd_[j][i];
     }
 #pragma unroll
@@ -695,6 +702,13 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < X_TX; ++i) cadd[j][i] = *reinterpret_cast<const u32x2*>(hb + cbase + 2 * j * X_PLANE + i * X_XSTRIDE);
+    } else if constexpr (CADD_LATE) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < X_TX; ++i)
+          *reinterpret_cast<u32x2*>(sCad + (((buf * NT + j) * X_TX + i) * NTHR + tid) * 8) =
+              *reinterpret_cast<const u32x2*>(hb + cbase + 2 * j * X_PLANE + i * X_XSTRIDE);
     } else if constexpr (ADD == 3 && !A1) {
       const int av = (2 * yp + pdy) * 8 + pz, asw = ACH == 4 ? ((av >> 2) & 3) : 0;       // (the swizzle of the DMA source side)
       const char* ab = sA + buf * ABUF + av * ACH * 16 + (q4 & 1) * 8;
@@ -736,6 +750,7 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
     for (int k = 0; k < 18; ++k) sLane[k * 64] = 0u;
   };
   int ce_n = -1;
+  float ce_coef = 0.f;
   auto ce_flush = [&](int n) {            // this workgroup's record of sample n (slot blockIdx.x) and its Dice counts
     const double a = wave_sum((double)ce_nll), b = wave_sum((double)ce_w);
     if (lane == 0) { sSum[2 * wave] = a; sSum[2 * wave + 1] = b; }
@@ -769,6 +784,9 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
     if (o.n != ce_n) {
       if (ce_n >= 0) ce_flush(ce_n);
       ce_n = o.n;
+      // the sample's gradient scale, ONCE per sample: read inside the per-tile arithmetic it was a global load whose full wait
+      // (vmcnt(0)) also drained the halo loads of the next tile, issued just before — every tile
+      ce_coef = E.coef[(int64_t)o.n * E.coef_stride];
     }
     // logits = conv + bias (+ identity residual), then a wave-local exchange through LDS: lane (r16, q4) ends up with the 12 values
     // of voxel r16 of x plane q4 (it held channels 4 q4 .. 4 q4 + 3 of all four planes)
@@ -811,20 +829,37 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
     //      maximal index, capstone/training/utils.py:19-20): the largest logit has e = exp(0) = 1 exactly, and another class can only
     //      tie with it after the division if its e is within an ulp of 1 — lanes that hold such a near-tie (rare; wave-uniform test)
     //      redo the softmax with expf and true divisions exactly as seg_loss_kernel does.
-    float m = x[0];
+    // Packed (two classes per instruction) arithmetic: this part is NOT hidden behind an HBM stream (tools/ablate_head_ce.sh: 0.28 of
+    // the launch's 0.79 ms), so the per-class selects of the first version (x[t], the one-hot of the gradient, the prediction scan,
+    // the near-tie count: ~100 compare / select pairs) are indicator products: clamp(1 + (x - m) * 2^100) is 1 exactly where
+    // x == m, clamp(1 - (c - t)^2) is the one-hot of the label.  Columns >= C carry a bias of -3e38 (set once, below): e = 0.
+    f32x2 xp[6], ep[6], dp[6];
 #pragma unroll
-    for (int c = 1; c < 12; ++c) if (c < C) m = fmaxf(m, x[c]);
-    float e[12], ssum = 0.f;
-    int pred = -1, near = 0;
+    for (int k = 0; k < 6; ++k) xp[k] = f32x2{x[2 * k], x[2 * k + 1]};
+    f32x2 mm = __builtin_elementwise_max(__builtin_elementwise_max(xp[0], xp[1]), __builtin_elementwise_max(xp[2], xp[3]));
+    mm = __builtin_elementwise_max(mm, __builtin_elementwise_max(xp[4], xp[5]));
+    const float m = fmaxf(mm[0], mm[1]);
+    const f32x2 m2 = {m, m}, zero2 = {0.f, 0.f}, one2 = {1.f, 1.f};
+    constexpr float BIG = 0x1p100f;
+    f32x2 pf2 = zero2, nr2 = zero2, ss2 = zero2;
 #pragma unroll
-    for (int c = 0; c < 12; ++c) {
-      e[c] = (c < C) ? __expf(x[c] - m) : 0.f;
-      if (c < C) {
-        ssum += e[c];
-        if (x[c] == m) { if (pred < 0) pred = c; }
-        near += e[c] > 0.999f ? 1 : 0;          // (the maximum itself counts once: e = 1)
-      }
+    for (int k = 0; k < 6; ++k) {
+      dp[k] = xp[k] - m2;                                              // <= 0, = 0 exactly at the maximum (so e = 1 exactly there)
+      ep[k] = f32x2{__expf(dp[k][0]), __expf(dp[k][1])};
+      ss2 += ep[k];
+      const f32x2 at_max = __builtin_elementwise_min(__builtin_elementwise_max(dp[k] * BIG + one2, zero2), one2);
+      // within 0.001 of the maximum <=> e > 0.999 (the maximum itself counts once): the trigger of the exact path below
+      const f32x2 close = __builtin_elementwise_min(__builtin_elementwise_max(dp[k] * BIG + (1.f + 0.0010005f * BIG), zero2), one2);
+      pf2 += at_max * f32x2{(float)(2 * k), (float)(2 * k + 1)};
+      nr2 += close;
     }
+    const float ssum = ss2[0] + ss2[1];
+    // no near-tie: exactly one class has x == m, the sum of c * [x_c == m] is its index
+    int pred = (int)(pf2[0] + pf2[1]);
+    const int near = (int)(nr2[0] + nr2[1]);
+    float e[12];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { e[2 * k] = ep[k][0]; e[2 * k + 1] = ep[k][1]; }
     if (!(X_ABL & 64) && __builtin_amdgcn_ballot_w64(near > 1) != 0ull) {
       if (near > 1) {
         float e2[12], s2 = 0.f;
@@ -841,9 +876,16 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
     }
     const float rs = __builtin_amdgcn_rcpf(ssum);                  // (gradient only: 1 ulp)
     const float lse = m + __logf(ssum);
-    float xt = 0.f;
+    // one-hot of the label as products: oh_c = clamp(1 - (c - t)^2); x_t = sum_c oh_c x_c (a column >= C has oh = 0 and a FINITE x)
+    const float tf = (float)t;
+    f32x2 oh[6], xt2 = zero2;
 #pragma unroll
-    for (int c = 0; c < 12; ++c) if (c == t) xt = x[c];
+    for (int k = 0; k < 6; ++k) {
+      const f32x2 dd = f32x2{(float)(2 * k), (float)(2 * k + 1)} - f32x2{tf, tf};
+      oh[k] = __builtin_elementwise_min(__builtin_elementwise_max(one2 - dd * dd, zero2), one2);
+      xt2 += oh[k] * xp[k];
+    }
+    const float xt = xt2[0] + xt2[1];
     const float w = (E.class_weight != nullptr && t < C) ? E.class_weight[t] : 1.f;
     if (valid) {
       ce_nll += w * (lse - xt);
@@ -861,10 +903,13 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
       atomicAdd(&sLane[(1 * 6 + wp) * 64], ip);
       if (pred == t) atomicAdd(&sLane[wp * 64], ip);
     }
-    const float ce_scale = E.coef[(int64_t)o.n * E.coef_stride] * w;
+    const float ce_scale = ce_coef * w;
     float d[12];
 #pragma unroll
-    for (int c = 0; c < 12; ++c) d[c] = (c < C) ? ce_scale * (e[c] * rs - ((c == t) ? 1.f : 0.f)) : 0.f;
+    for (int k = 0; k < 6; ++k) {
+      const f32x2 g2 = (ep[k] * f32x2{rs, rs} - oh[k]) * f32x2{ce_scale, ce_scale};     // (columns >= C: e = 0, oh = 0)
+      d[2 * k] = g2[0]; d[2 * k + 1] = g2[1];
+    }
     if ((X_ABL & 16) ? (valid && d[0] + d[5] == 123.f) : valid) {
       char* gp = E.dlogits + vox * E.g_ld * 2;
 #pragma unroll

@@ -14,8 +14,9 @@ void set_error(const char* fmt, ...) {
 // torch.optim.Adam (amsgrad=False, weight_decay=0) as torch applies it:
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                   float* __restrict__ v, int64_t n, float omb1, float b2, float omb2, float eps,
                                                    float step_size, float bc2_sqrt, float gscale) {
+  // omb1 = 1 - beta1, omb2 = 1 - beta2 as torch forms them: in DOUBLE on the host, then rounded (1.f - 0.999f is 1.3e-5 off 0.001)
   const int64_t n4 = n / 4;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
@@ -23,8 +24,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float gr = gg[e] * gscale;
-      mm[e] = mm[e] + (gr - mm[e]) * (1.f - b1);  // torch: exp_avg.lerp_(grad, 1 - beta1)
-      vv[e] = vv[e] * b2 + (1.f - b2) * gr * gr;
+      mm[e] = mm[e] + (gr - mm[e]) * omb1;  // torch: exp_avg.lerp_(grad, 1 - beta1)
+      vv[e] = vv[e] * b2 + omb2 * gr * gr;
       const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
       pp[e] = pp[e] - step_size * (mm[e] / denom);
     }
@@ -35,8 +36,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = n4 * 4 + threadIdx.x;
     const float gr = g[i] * gscale;
-    const float mm = m[i] + (gr - m[i]) * (1.f - b1);
-    const float vv = v[i] * b2 + (1.f - b2) * gr * gr;
+    const float mm = m[i] + (gr - m[i]) * omb1;
+    const float vv = v[i] * b2 + omb2 * gr * gr;
     m[i] = mm; v[i] = vv;
     p[i] = p[i] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
   }
@@ -197,15 +198,15 @@ using namespace ctseg;
 extern "C" int ctseg_abi_version(void) { return CTSEG_ABI_VERSION; }
 extern "C" const char* ctseg_last_error(void) { return g_err; }
 
-extern "C" int ctseg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                               float eps, int32_t step, float grad_scale, void* stream) {
+extern "C" int ctseg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                               double eps, int32_t step, float grad_scale, void* stream) {
   CTSEG_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
   CTSEG_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
                 "adam_step: buffers must be 16-byte aligned");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
-  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n / 4 + 1, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                     beta2, eps, step_size, bc2_sqrt, grad_scale);
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n / 4 + 1, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2_sqrt, grad_scale);
   CTSEG_LAUNCH_CHECK("adam_step");
   return 0;
 }

@@ -259,8 +259,9 @@ int ctseg_reduce_partials_f64(const double* part, int32_t B, int32_t P, int32_t 
  * samples whose truth holds it (0 if none), from cnt[B][3][C]; out[1] = mean of those C-1 values.  out: 1 + C floats. */
 int ctseg_loss_dice_summary(const double* red, int32_t B, int32_t R, const int64_t* cnt, int32_t C, float* out, void* stream);
 
-/* torch.optim.Adam step (capstone/volumetric/base_trainer.py:113-114) on flat fp32 buffers. */
-int ctseg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+/* torch.optim.Adam step (capstone/volumetric/base_trainer.py:113-114) on flat fp32 buffers.  lr / betas / eps are doubles (ABI 3),
+ * as the Python floats torch receives: 1 - beta2 is formed in double and THEN rounded (0.001f; 1.f - 0.999f is 1.3e-5 off). */
+int ctseg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                     int32_t step, float grad_scale, void* stream);
 
 /* x[0..n) *= host_scale * (dev_scale ? *dev_scale : 1), in place; a launch whose factor is exactly 1 touches no memory.
