@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round artefacts on the GPU box (run from the repo root): rocprofv3 kernel stats of the bench command, per-op table, PMC passes of
 # the bottleneck launch, sliding-window timings.  Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p $O
