@@ -230,9 +230,10 @@ def main():
         orig_run = plan.run
 
         def run_probed(prog, stream, lo=0, hi=None):
-            if prog is plan.fwd:
+            end = len(prog) if hi is None else hi       # (the forward may arrive in pieces: [0, 1) and [1, end) behind the split repack)
+            if prog is plan.fwd and lo <= probe_i < end:
                 a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                orig_run(prog, stream, 0, probe_i)
+                orig_run(prog, stream, lo, probe_i)
                 a.record()
                 orig_run(prog, stream, probe_i, probe_i + 1)
                 b.record()

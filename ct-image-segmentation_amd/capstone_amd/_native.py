@@ -76,6 +76,20 @@ class ConvDesc(_SizedDesc):
                 ("reserved1", C.c_int32)]
 
 
+class PackPart(C.Structure):
+    _fields_ = [("o", C.c_int64), ("n_lo", C.c_int32), ("n_hi", C.c_int32), ("g_lo", C.c_int32), ("g_hi", C.c_int32),
+                ("SN", C.c_int32), ("SG", C.c_int32)]
+
+
+class PackBlock(C.Structure):
+    _fields_ = [("dst_off", C.c_int64), ("kpad", C.c_int32), ("gs", C.c_int32), ("ntaps", C.c_int32), ("T", C.c_int32),
+                ("nparts", C.c_int32), ("reserved", C.c_int32), ("part", PackPart * 2), ("tap", C.c_int32 * MAX_TAPS),
+                ("reserved2", C.c_int32)]
+
+
+PACK_LDS_FLOATS = 12288
+
+
 class WgradDesc(_SizedDesc):
     _fields_ = [("struct_size", C.c_int32), ("reserved0", C.c_int32), ("in_", C.c_void_p), ("dy", C.c_void_p), ("ws", C.c_void_p), ("dtype", C.c_int32),
                 ("N", C.c_int32), ("Xi", C.c_int32), ("Yi", C.c_int32), ("Zi", C.c_int32),
@@ -105,6 +119,7 @@ _SIGS = {
     "ctseg_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
     "ctseg_conv_wgrad_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ctseg_gather_cast": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp]),
+    "ctseg_pack_weights": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
     "ctseg_instnorm_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp]),
     "ctseg_instnorm_prelu_fwd": (C.c_int, [_i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp]),
     "ctseg_instnorm_prelu_bwd_reduce": (C.c_int, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),

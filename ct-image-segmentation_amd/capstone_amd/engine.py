@@ -279,6 +279,23 @@ class GemmLayer:
             idx = np.where(m, v, idx)
         return idx
 
+    def src_parts(self, mode):
+        """the same mapping as src_index, structured (ctseg_pack_part): [(o, n_lo, n_hi, g_lo, g_hi, SN, SG)] with
+        source(n, g, t) = o + (n - n_lo) * SN + (g - g_lo) * SG + t for (n, g) inside the ranges"""
+        st, cin, T = self.plan.store, self.cin, self.T
+        out = []
+        if not self.transposed:
+            r0 = 0
+            for w, _, cout in self.parts:
+                o = st.off(w)
+                out.append((o, r0, r0 + cout, 0, cin, cin * T, T) if mode == "fwd" else (o, 0, cin, r0, r0 + cout, T, cin * T))
+                r0 += cout
+        else:
+            w, _, cout = self.parts[0]
+            o = st.off(w)
+            out.append((o, 0, cout, 0, cin, T, cout * T) if mode == "fwd" else (o, 0, cin, 0, cout, cout * T, T))
+        return out
+
     def rows_gather(self, mode):
         """(real GEMM rows, gathered channel stride) for a pack mode"""
         return (self.Cn, self.cg) if mode == "fwd" else (self.cin, self.cgd)
@@ -523,6 +540,7 @@ class Packer:
     def __init__(self, plan):
         self.plan = plan
         self.blocks = []      # (offset, np index array)
+        self.descs = []       # the same blocks as ctseg_pack_block descriptions
         self.total = 0
         self.bias_blocks, self.bias_total = [], 0
         self.buf = self.idx = self.bias_buf = self.bias_idx = None
@@ -549,7 +567,21 @@ class Packer:
             info["kpads"].append(kpad)
             info["w_offs"].append(self.total - info["base"])
             self.blocks.append((self.total, blk.reshape(-1)))
+            # the same block, structured (ctseg_pack_weights): checked against the index above element by element
+            parts = layer.src_parts(mode)
+            desc = {"dst_off": self.total, "kpad": kpad, "gs": gs, "ntaps": nt, "T": layer.T, "taps": [t for t, _ in taps],
+                    "parts": parts, "rows": rows}
+            if os.environ.get("CTSEG_PACK_CHECK", "1") != "0":
+                chk = np.full((rows_pad, kpad), zero, dtype=np.int64)
+                for (o, n_lo, n_hi, g_lo, g_hi, SN, SG) in parts:
+                    nn, gg = np.arange(n_lo, min(n_hi, rows)), np.arange(g_lo, min(g_hi, gs))
+                    for j, t in enumerate(desc["taps"]):
+                        chk[n_lo:n_lo + len(nn), j * gs + g_lo:j * gs + g_lo + len(gg)] = \
+                            o + (nn[:, None] - n_lo) * SN + (gg[None, :] - g_lo) * SG + t
+                assert np.array_equal(chk, blk), f"{layer.name} {mode}: structured pack description disagrees with the index"
+            self.descs.append(desc)
             self.total += rows_pad * kpad
+        info["size"] = self.total - info["base"]
         return info
 
     def add_bias(self, layer):
@@ -588,12 +620,55 @@ class Packer:
         self.bias_idx = torch.from_numpy(bidx).to(dev)
         self.n_idx, self.n_bidx = self.total, max(self.bias_total, 4)
         self.dirty = True
+        # structured re-layout (ctseg_pack_weights) where every block's source region fits its LDS staging buffer
+        self.pack_blocks = self.pack_rows = None
+        fits = all(sum((min(gh, d["gs"]) - gl) * d["T"] for (_, _, _, gl, gh, _, _) in d["parts"]) <= nat.PACK_LDS_FLOATS and
+                   len(d["parts"]) <= 2 for d in self.descs)
+        if self.descs and fits and os.environ.get("CTSEG_PACK_STRUCTURED", "1") != "0":
+            arr = (nat.PackBlock * len(self.descs))()
+            rows = []
+            for b, d in enumerate(self.descs):
+                B = arr[b]
+                B.dst_off, B.kpad, B.gs, B.ntaps, B.T, B.nparts = d["dst_off"], d["kpad"], d["gs"], d["ntaps"], d["T"], len(d["parts"])
+                for j, t in enumerate(d["taps"]):
+                    B.tap[j] = t
+                for k, (o, n_lo, n_hi, g_lo, g_hi, SN, SG) in enumerate(d["parts"]):
+                    P = B.part[k]
+                    P.o, P.n_lo, P.n_hi, P.g_lo, P.g_hi, P.SN, P.SG = o, n_lo, n_hi, g_lo, min(g_hi, d["gs"]), SN, SG
+                rows += [(b, n) for n in range(d["rows"])]
+            import ctypes
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+            self.pack_blocks = raw.to(dev)
+            # rows of the blocks of the FIRST forward pass first (Packer.first = its pack): refresh(part="first") rebuilds them alone,
+            # the next step's first convolution waits for nothing else
+            lo, hi = self.first if getattr(self, "first", None) else (0, 0)
+            head = [(b, n) for (b, n) in rows if lo <= self.descs[b]["dst_off"] < hi]
+            rest = [(b, n) for (b, n) in rows if not (lo <= self.descs[b]["dst_off"] < hi)]
+            self.n_first_rows = len(head)
+            self.pack_rows = torch.tensor(head + rest, dtype=torch.int32).reshape(-1).to(dev)
+            self.n_pack_blocks, self.n_pack_rows = len(self.descs), len(rows)
 
-    def refresh(self, force=False):
+    def can_split(self):
+        """True when refresh(part="first") / refresh(part="rest") can rebuild the first forward pass's operands on their own"""
+        return self.pack_blocks is not None and getattr(self, "n_first_rows", 0) > 0
+
+    def refresh(self, force=False, part=None):
+        """part: None = everything; "first" = the biases and the packed operands of the first forward pass; "rest" = the others
+        (the pair, in that order, equals None)"""
         st = self.plan.store
         ver = st.version()
         if not (force or self.dirty or ver != self.version):
             return
-        nat.call("ctseg_gather_cast", st.flat_p.data_ptr(), self.idx.data_ptr(), self.buf.data_ptr(), self.plan.dt, self.n_idx)
-        nat.call("ctseg_gather_cast", st.flat_p.data_ptr(), self.bias_idx.data_ptr(), self.bias_buf.data_ptr(), F32, self.n_bidx)
-        self.dirty, self.version = False, ver
+        if self.pack_blocks is not None:
+            # (padding rows / K slots beyond ntaps * gs of a real row: the former keep the zeros of the allocation, the latter are
+            # written as zeros by the row's workgroup)
+            lo, hi = {None: (0, self.n_pack_rows), "first": (0, self.n_first_rows), "rest": (self.n_first_rows, self.n_pack_rows)}[part]
+            if hi > lo:
+                nat.call("ctseg_pack_weights", st.flat_p.data_ptr(), self.pack_blocks.data_ptr(), self.n_pack_blocks,
+                         self.pack_rows.data_ptr() + 8 * lo, hi - lo, self.buf.data_ptr(), self.plan.dt)
+        elif part != "rest":
+            nat.call("ctseg_gather_cast", st.flat_p.data_ptr(), self.idx.data_ptr(), self.buf.data_ptr(), self.plan.dt, self.n_idx)
+        if part != "rest":
+            nat.call("ctseg_gather_cast", st.flat_p.data_ptr(), self.bias_idx.data_ptr(), self.bias_buf.data_ptr(), F32, self.n_bidx)
+        if part != "first":
+            self.dirty, self.version = False, ver

@@ -407,6 +407,9 @@ class Plan:
         self.shape = (N, X, Y, Z)
         cin = net.in_channels
         self.root = _Level(self, net.model, "model", cin, True)
+        # the pack of the first forward pass (the stem): rebuilt first after an optimizer step, see repack_after_update
+        first = self.root.down.gemms[0] if hasattr(self.root.down, "gemms") else self.root.down.gemm
+        self.packer.first = (first.fwd_pack["base"], first.fwd_pack["base"] + first.fwd_pack["size"])
         self.packer.finalize()
         self.norm_bwd = []
         # ---- record programs ----
@@ -488,8 +491,16 @@ class Plan:
         main = torch.cuda.current_stream(self.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            self.packer.refresh(force=True)
-            self._repack_ev = side.record_event()
+            if self.packer.can_split() and os.environ.get("CTSEG_REPACK_SPLIT", "1") != "0":
+                # the next step's first convolution needs its own operand and the biases only: everything else is rebuilt BESIDE
+                # that convolution (the whole re-layout sat on the critical path between two steps: Adam -> repack -> stem)
+                self.packer.refresh(force=True, part="first")
+                self._repack_ev = side.record_event()
+                self.packer.refresh(force=True, part="rest")
+                self._repack_ev2 = side.record_event()
+            else:
+                self.packer.refresh(force=True)
+                self._repack_ev = side.record_event()
 
     def head_ce_slots(self, n_classes):
         """partial-sum slots per sample of ctseg_conv_logits_ce for this plan's logits convolution (0: not eligible — the
@@ -515,7 +526,15 @@ class Plan:
             self._repack_ev = None
         self.packer.refresh()
         self.fwd_gen += 1
-        self.run(self.fwd, nat.stream_ptr(), 0, len(self.fwd) - 1 if skip_head else None)
+        end = len(self.fwd) - 1 if skip_head else None
+        ev2 = getattr(self, "_repack_ev2", None)
+        if ev2 is not None:
+            self._repack_ev2 = None
+            self.run(self.fwd, nat.stream_ptr(), 0, 1)           # the first pass (its operand is ready: _repack_ev)
+            torch.cuda.current_stream(self.device).wait_event(ev2)
+            self.run(self.fwd, nat.stream_ptr(), 1, end)
+        else:
+            self.run(self.fwd, nat.stream_ptr(), 0, end)
         self.logits_current = not skip_head
         return self.logits
 

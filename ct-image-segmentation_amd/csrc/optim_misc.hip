@@ -67,6 +67,88 @@ template <typename TS, typename TD> __global__ void cast_kernel(const TS* __rest
     d[i] = cvt<TS, TD>(s[i]);
 }
 
+// structured weight re-layout (ctseg_pack_weights): one workgroup per (block, row)
+template <typename TD> __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ src,
+                                                                                  const ctseg_pack_block* __restrict__ blocks,
+                                                                                  const int32_t* __restrict__ rows, TD* __restrict__ dst) {
+  __shared__ float s_w[CTSEG_PACK_LDS_FLOATS];     // the row's source region(s): (g_hi - g_lo) * T floats per part (caller-checked)
+  const int b = rows[2 * blockIdx.x], n = rows[2 * blockIdx.x + 1];
+  const ctseg_pack_block& B = blocks[b];
+  const int T = B.T;
+  int loff[2] = {0, 0};
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (p < B.nparts) {
+      const ctseg_pack_part& P = B.part[p];
+      if (p == 1) loff[1] = (B.part[0].g_hi - B.part[0].g_lo) * T;
+      if (n >= P.n_lo && n < P.n_hi) {
+        const int cnt = (P.g_hi - P.g_lo) * T;
+        const float* base = src + P.o + (int64_t)(n - P.n_lo) * P.SN;
+        // (batches of 8 independent loads: the longest rows — 384 gathered channels x 27 taps — would otherwise pay ~40 dependent
+        // round trips through this loop)
+        for (int i0 = threadIdx.x; i0 < cnt; i0 += 256 * 8) {
+          float r[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            const int g = i / T, t = i - g * T;
+            r[u] = i < cnt ? base[(int64_t)g * P.SG + t] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (i0 + u * 256 < cnt) s_w[loff[p] + i0 + u * 256] = r[u];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  TD* drow = dst + B.dst_off + (int64_t)n * B.kpad;
+  const int used = B.ntaps * B.gs;
+  // eight consecutive K slots per thread: when gs is a multiple of 8 (every pass with 16-byte chunked rows) they share their tap and
+  // their gathered channels are consecutive: one division per 16 bytes stored (2-byte stores moved 128 bytes per wave instruction)
+  if (B.gs % 8 == 0 && B.kpad % 8 == 0) {
+    for (int k0 = threadIdx.x * 8; k0 < B.kpad; k0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      if (k0 < used) {
+        const int j = k0 / B.gs, g0 = k0 - j * B.gs, tp = B.tap[j];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          if (p < B.nparts && n >= B.part[p].n_lo && n < B.part[p].n_hi) {
+            const int g_lo = B.part[p].g_lo, g_hi = B.part[p].g_hi;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (g0 + e >= g_lo && g0 + e < g_hi) v[e] = s_w[loff[p] + (g0 + e - g_lo) * T + tp];
+          }
+      }
+      if constexpr (sizeof(TD) == 4) {
+        reinterpret_cast<f32x4*>(drow + k0)[0] = f32x4{v[0], v[1], v[2], v[3]};
+        reinterpret_cast<f32x4*>(drow + k0)[1] = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = (uint32_t)__builtin_bit_cast(unsigned short, cvt<float, TD>(v[2 * e])) |
+                 ((uint32_t)__builtin_bit_cast(unsigned short, cvt<float, TD>(v[2 * e + 1])) << 16);
+        *reinterpret_cast<u32x4*>(drow + k0) = o;
+      }
+    }
+    return;
+  }
+  for (int k = threadIdx.x; k < B.kpad; k += 256) {
+    float v = 0.f;
+    if (k < used) {
+      const int j = k / B.gs, g = k - j * B.gs;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        if (p < B.nparts && n >= B.part[p].n_lo && n < B.part[p].n_hi && g >= B.part[p].g_lo && g < B.part[p].g_hi)
+          v = s_w[loff[p] + (g - B.part[p].g_lo) * T + B.tap[j]];
+    }
+    drow[k] = cvt<float, TD>(v);
+  }
+}
+
 // fp32 [N][C][S] -> [N][S][ld]; thread per (voxel, channel<ld): reads strided by S, writes contiguous (small C only)
 template <typename TD> __global__ void nc_to_cl_kernel(const float* __restrict__ s, TD* __restrict__ d, int C, int64_t S, int ld) {
   const int n = blockIdx.y;
@@ -76,6 +158,25 @@ template <typename TD> __global__ void nc_to_cl_kernel(const float* __restrict__
     const int c = (int)(i - v * ld);
     const float x = c < C ? s[((int64_t)n * C + c) * S + v] : 0.f;
     d[(int64_t)n * total + i] = cvt<float, TD>(x);
+  }
+}
+// C == ld == 1 (the U-Net's one-channel input): a plain cast, 8 elements per thread (two 16-byte loads, one 16-byte store of
+// 16-bit storage).  The general kernel above does a 64-bit division and a 2-byte store per element: 95 us for the 100 MB batch,
+// on the critical path between two training steps (the next stem convolution waits for it).
+template <typename TD> __global__ __launch_bounds__(256) void cast8_kernel(const float* __restrict__ s, TD* __restrict__ d, int64_t n8) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(s)[2 * i], b = reinterpret_cast<const f32x4*>(s)[2 * i + 1];
+    if constexpr (sizeof(TD) == 4) {
+      reinterpret_cast<f32x4*>(d)[2 * i] = a;
+      reinterpret_cast<f32x4*>(d)[2 * i + 1] = b;
+    } else {
+      u32x4 o;
+      o[0] = (uint32_t)__builtin_bit_cast(unsigned short, cvt<float, TD>(a[0])) | ((uint32_t)__builtin_bit_cast(unsigned short, cvt<float, TD>(a[1])) << 16);
+      o[1] = (uint32_t)__builtin_bit_cast(unsigned short, cvt<float, TD>(a[2])) | ((uint32_t)__builtin_bit_cast(unsigned short, cvt<float, TD>(a[3])) << 16);
+      o[2] = (uint32_t)__builtin_bit_cast(unsigned short, cvt<float, TD>(b[0])) | ((uint32_t)__builtin_bit_cast(unsigned short, cvt<float, TD>(b[1])) << 16);
+      o[3] = (uint32_t)__builtin_bit_cast(unsigned short, cvt<float, TD>(b[2])) | ((uint32_t)__builtin_bit_cast(unsigned short, cvt<float, TD>(b[3])) << 16);
+      reinterpret_cast<u32x4*>(d)[i] = o;
+    }
   }
 }
 template <typename TS> __global__ void cl_to_nc_kernel(const TS* __restrict__ s, float* __restrict__ d, int C, int64_t S, int ld) {
@@ -291,11 +392,32 @@ extern "C" int ctseg_cast(const void* src, int32_t sd, void* dst, int32_t dd, in
 extern "C" int ctseg_nc_to_cl(const float* src, void* dst, int32_t dtype, int32_t N, int32_t C, int64_t S, int32_t ld,
                               void* stream) {
   CTSEG_REQUIRE(src && dst && N > 0 && C > 0 && S > 0 && ld >= C, "nc_to_cl: bad arguments");
+  if (C == 1 && ld == 1 && ((int64_t)N * S) % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
+    const int64_t n8 = (int64_t)N * S / 8;
+    const dim3 g8(nblocks(n8 * 256 / 256, 8192));
+    if (dtype == CTSEG_F32) hipLaunchKernelGGL(cast8_kernel<float>, g8, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, n8);
+    else if (dtype == CTSEG_F16) hipLaunchKernelGGL(cast8_kernel<_Float16>, g8, dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, n8);
+    else hipLaunchKernelGGL(cast8_kernel<unsigned short>, g8, dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, n8);
+    CTSEG_LAUNCH_CHECK("nc_to_cl");
+    return 0;
+  }
   dim3 grid(nblocks(S * ld), N);
   if (dtype == CTSEG_F32) hipLaunchKernelGGL(nc_to_cl_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, C, S, ld);
   else if (dtype == CTSEG_F16) hipLaunchKernelGGL(nc_to_cl_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, C, S, ld);
   else hipLaunchKernelGGL(nc_to_cl_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, C, S, ld);
   CTSEG_LAUNCH_CHECK("nc_to_cl");
+  return 0;
+}
+
+extern "C" int ctseg_pack_weights(const float* src, const ctseg_pack_block* blocks, int32_t n_blocks, const int32_t* rows, int32_t n_rows,
+                                  void* dst, int32_t dtype, void* stream) {
+  CTSEG_REQUIRE(src && blocks && rows && dst && n_blocks > 0 && n_rows > 0, "pack_weights: bad arguments");
+  CTSEG_REQUIRE(dtype == CTSEG_F32 || is16(dtype), "pack_weights: bad dtype %d", dtype);
+  const dim3 grid((unsigned)n_rows);
+  if (dtype == CTSEG_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, blocks, rows, (float*)dst);
+  else if (dtype == CTSEG_F16) hipLaunchKernelGGL(pack_weights_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, src, blocks, rows, (_Float16*)dst);
+  else hipLaunchKernelGGL(pack_weights_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, src, blocks, rows, (unsigned short*)dst);
+  CTSEG_LAUNCH_CHECK("pack_weights");
   return 0;
 }
 

@@ -176,6 +176,31 @@ int ctseg_conv_wgrad_reduce(const float* ws, int32_t nslabs, int32_t kpad_w, int
  * ONE launch per optimizer step; pad entries point at a zero element of src. */
 int ctseg_gather_cast(const float* src, const int32_t* idx, void* dst, int32_t dtype, int64_t n, void* stream);
 
+/* The same re-layout, structured (ABI 3): one [rows][kpad] block of a packed operand is described instead of indexed element by
+ * element.  Packed element (row n, K slot j * gs + g) of a block is the weight src[part.o + (n - part.n_lo) * part.SN +
+ * (g - part.g_lo) * part.SG + tap[j]] of the part whose row / gathered-channel ranges hold (n, g), zero when no part does or
+ * j >= ntaps.  A workgroup takes one row: it reads the row's source region in T-element runs (contiguous when SG == T) into LDS
+ * and writes the K-contiguous row from there -- 25 MB written for ~40 MB read, where the index-driven gather reads 450 MB (every
+ * gathered element sits in another cache line: consecutive K slots are T elements apart in torch's [out][in][taps] layout).
+ * `rows` lists (block, row) pairs (device int32[2 * n_rows]); rows it does not list are never written (padding rows stay at the
+ * zeros the caller initialised them with).  Device arrays; dtype = storage of dst (CTSEG_F32 / BF16 / F16). */
+#define CTSEG_PACK_LDS_FLOATS 12288 /* sum over a block's parts of (g_hi - g_lo) * T must not exceed this (48 KB of LDS) */
+typedef struct ctseg_pack_part {
+  int64_t o;                     /* element offset of the weight tensor in src                          */
+  int32_t n_lo, n_hi, g_lo, g_hi; /* rows / gathered channels this tensor supplies                       */
+  int32_t SN, SG;                /* source strides (elements) of the row and of the gathered channel     */
+} ctseg_pack_part;
+typedef struct ctseg_pack_block {
+  int64_t dst_off;               /* element offset of the block in dst                                   */
+  int32_t kpad, gs, ntaps, T;    /* row pitch, gathered-channel stride, K slots in use = ntaps * gs, taps of the source weight */
+  int32_t nparts, reserved;
+  ctseg_pack_part part[2];
+  int32_t tap[CTSEG_MAX_TAPS];   /* source tap id of K-slot group j                                      */
+  int32_t reserved2;
+} ctseg_pack_block;
+int ctseg_pack_weights(const float* src, const ctseg_pack_block* blocks, int32_t n_blocks, const int32_t* rows, int32_t n_rows,
+                       void* dst, int32_t dtype, void* stream);
+
 /* InstanceNorm3d(affine=False, eps) + PReLU(1 scalar), as MONAI's Convolution block applies them
  * (SURVEY.md §3.2).  Statistics come from the conv pass's partials. */
 /* partials [N][P][2][ld] fp32 -> mean_rstd [N][C][2] fp32 (biased variance, fp64 combine, fixed order) */

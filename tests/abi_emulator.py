@@ -140,6 +140,33 @@ class Emulator:
         if db:
             mem(db, nb)[:] = w[T * AS, col0:col0 + nb]
 
+    def pack_weights(self, src, blocks, n_blocks, rows, n_rows, dst, dtype):
+        """ctseg_pack_weights: the structured re-layout, row by row as the kernel does it"""
+        import sys
+        nat = sys.modules["capstone_amd._native"]
+        assert dtype == F32
+        arr = (nat.PackBlock * n_blocks).from_address(blocks)
+        rw = mem(rows, 2 * n_rows, np.int32).reshape(n_rows, 2)
+        hi = max(int(arr[b].part[k].o + (arr[b].part[k].n_hi - arr[b].part[k].n_lo) * arr[b].part[k].SN +
+                     (arr[b].part[k].g_hi - arr[b].part[k].g_lo) * arr[b].part[k].SG + arr[b].T)
+                 for b in range(n_blocks) for k in range(arr[b].nparts))
+        S = mem(src, hi)
+        for b in range(n_blocks):
+            B = arr[b]
+            mine = rw[rw[:, 0] == b, 1]
+            if len(mine) == 0:
+                continue
+            D = mem(dst + 4 * B.dst_off, (int(mine.max()) + 1) * B.kpad).reshape(-1, B.kpad)
+            for n in mine:
+                row = np.zeros(B.kpad, np.float32)
+                for k in range(B.nparts):
+                    P = B.part[k]
+                    if P.n_lo <= n < P.n_hi:
+                        g = np.arange(P.g_lo, P.g_hi)
+                        for j in range(B.ntaps):
+                            row[j * B.gs + g] = S[P.o + (n - P.n_lo) * P.SN + (g - P.g_lo) * P.SG + B.tap[j]]
+                D[n] = row
+
     def gather_cast(self, src, idx, dst, dtype, n):
         assert dtype == F32
         i = mem(idx, n, np.int32)
