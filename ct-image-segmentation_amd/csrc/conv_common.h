@@ -92,7 +92,10 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4
 // workgroup tile, channels wn*WTN + j*16 + 4*q4 + {0..3}.  sRow[2r] = xr | yr<<16, sRow[2r+1] = zr (or < 0: no voxel).
 // + bias, per-(tile, channel) sum / sumsq partials, transpose through LDS (`smem`, BM*(BN*OSZ+16) bytes),
 // optional addend, 16-byte coalesced channels-last stores.  Ends with all LDS reads done but NO trailing barrier.
-template <typename T, int BM, int BN, int WGM, int WGN>
+// BST (compile time): the instantiation that can take ConvKArgs::bst.  It is a kernel of its own because its epilogue holds 50 more
+// registers than the main loop needs (128 x 64 tile: 108 -> 180, three -> two workgroups per CU: +29 % on the 8-class forward pass
+// that never asks for the statistics, when the flag was a run-time one).
+template <typename T, int BM, int BN, int WGM, int WGN, bool BST = false>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_conv_class& K, char* smem, float* sStats,
                                               const int* sRow, f32x4 (&acc)[BN / WGN / 16][BM / WGM / 16], int n, int tile,
                                               int cls_index, int col0) {
@@ -161,7 +164,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& P, const ctseg_co
   }
   // backward InstanceNorm statistics of the stored gradient (ConvKArgs::bst): a thread keeps ONE 8-channel chunk column through the
   // store loop below (NTHR is a multiple of the chunks per row), so its 8 + 8 + 1 sums stay in registers for the whole tile
-  const bool bst = SZ == 2 && !of32 && P.bst.part != nullptr;
+  const bool bst = BST && SZ == 2 && !of32 && P.bst.part != nullptr;
   f32x2 q_rs[4], q_nm[4], q1[4], q2[4];
   float q3 = 0.f, q_al = 1.f;
   int q_ch0 = 0;                                  // channel of the norm the thread's chunk starts at (may be < 0 or >= C: not a channel)

@@ -15,6 +15,7 @@
 #include <utility>
 
 #include "conv_common.h"
+#include <type_traits>
 
 namespace ctseg {
 
@@ -32,7 +33,7 @@ template <int BM, int BN, int CSZ = 4> struct ConvSmem {
 // 16 zero bytes in device memory: the source of padded (out-of-tensor) operand chunks for direct-to-LDS loads
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool SMALLC>
+template <typename T, int BM, int BN, int WGM, int WGN, bool SMALLC, bool BST = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvKArgs P) {
   constexpr int NTHR = 64 * WGM * WGN;     // 4 waves, or 8 for the 192x256 bf16 tile (never fp32 output: CSZ = 2)
   constexpr int SZ = TT<T>::SZ, EPC = TT<T>::EPC;
@@ -268,13 +269,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvKA
     }
   }
 
-  conv_epilogue<T, BM, BN, WGM, WGN>(P, K, smem, sStats, sRow, acc, n, tile, (int)blockIdx.z, col0);
+  conv_epilogue<T, BM, BN, WGM, WGN, BST>(P, K, smem, sStats, sRow, acc, n, tile, (int)blockIdx.z, col0);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN>
 static int launch_cfg(const ConvKArgs& a, bool smallc, int nclass, hipStream_t st) {
   const int gx = a.xcd_order ? 8 * ((a.tiles * a.N + 7) / 8) : a.tiles * a.N;
   dim3 grid((unsigned)gx, (unsigned)((a.Cn + BN - 1) / BN), (unsigned)nclass);
+  if constexpr (std::is_same<T, BF16>::value) {       // backward statistics (training storage, 16-byte chunked operands: host-checked)
+    if (a.bst.part != nullptr) {
+      hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, false, true>), grid, dim3(64 * WGM * WGN), 0, st, a);
+      return 0;
+    }
+  }
   if (smallc) hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, true>), grid, dim3(64 * WGM * WGN), 0, st, a);
   else hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, false>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return 0;
@@ -308,6 +315,9 @@ static int bst_slots_for(const ConvKArgs& a, int dtype, int nclass, bool smallc)
       ((uintptr_t)a.bst.y % 16) != 0 || a.bst.col0 + a.bst.C > a.Cn_store)
     return 0;
   const int bm = tile_rows_for(a, dtype, smallc, nclass);
+  // (not the 128 x 64 / 256 x 32 / 256 x 16 tiles: the sums cost them a workgroup per CU — 108 -> 180 registers — which is what the
+  // reduce pass they would remove costs: 0.121 vs 0.092 + 0.024 ms on the 8-class 256 -> 64 pass)
+  if (bm != 192 && a.Cn <= 64) return 0;
   return ((a.rows + bm - 1) / bm) * nclass;
 }
 

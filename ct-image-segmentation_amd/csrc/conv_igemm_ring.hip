@@ -174,7 +174,7 @@ __device__ __forceinline__ void ring_main(const ConvKArgs& P, const ctseg_conv_c
   static_assert(D == 5, "the drain above is written for a five-deep ring");
 }
 
-template <typename H, int BN>     // H = 16-bit storage kind (BF16 / F16): the only difference is the MFMA and the epilogue's conversions
+template <typename H, int BN, bool BST = false>     // H = 16-bit storage kind (BF16 / F16): the only difference is the MFMA and the epilogue's conversions
 __global__ __launch_bounds__(512) void conv_igemm_ring_kernel(const ConvKArgs P) {
   using C = RingCfgT<BN>;
   constexpr int BM = C::BM, MT = BM / C::WGM / 16;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ring_kernel(const ConvKArgs P)
   else ring_main<H, BN, 1>(P, K, smem, sRow, sTap, acc, n, col0, wave, lane);
   __syncthreads();
 
-  conv_epilogue<H, BM, BN, C::WGM, C::WGN>(P, K, smem, sStats, sRow, acc, n, tile, (int)blockIdx.z, col0);
+  conv_epilogue<H, BM, BN, C::WGM, C::WGN, BST>(P, K, smem, sStats, sRow, acc, n, tile, (int)blockIdx.z, col0);
 }
 
 bool conv_ring_eligible(const ConvKArgs& a, int dtype, int nclass) {
@@ -246,10 +246,12 @@ void launch_conv_ring(const ConvKArgs& a, int nclass, hipStream_t st) {
   if (a.Cn > 128) {
     dim3 grid((unsigned)gx, (unsigned)((a.Cn + 255) / 256), (unsigned)nclass);
     if (a.dtype == CTSEG_F16) hipLaunchKernelGGL((conv_igemm_ring_kernel<F16, 256>), grid, dim3(512), 0, st, a);
+    else if (a.bst.part != nullptr) hipLaunchKernelGGL((conv_igemm_ring_kernel<BF16, 256, true>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((conv_igemm_ring_kernel<BF16, 256>), grid, dim3(512), 0, st, a);
   } else {
     dim3 grid((unsigned)gx, 1u, (unsigned)nclass);
     if (a.dtype == CTSEG_F16) hipLaunchKernelGGL((conv_igemm_ring_kernel<F16, 128>), grid, dim3(512), 0, st, a);
+    else if (a.bst.part != nullptr) hipLaunchKernelGGL((conv_igemm_ring_kernel<BF16, 128, true>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((conv_igemm_ring_kernel<BF16, 128>), grid, dim3(512), 0, st, a);
   }
 }
