@@ -12,6 +12,9 @@
 #include "conv_common.h"
 #include <type_traits>
 
+#ifndef UP_DELTA
+#define UP_DELTA 1   // 1: delta-major schedule (shifted fragments read once per K chunk for all classes of a wave half); 0: class by class
+#endif
 #ifndef UP_ABL
 #define UP_ABL 0     // timing-only ablation: 1 no MFMAs, 2 no LDS operand reads, 8 no output stores, 16 no halo loads
 #endif
@@ -24,6 +27,16 @@ constexpr int U_FV = 5 * 9 * 9;   // voxels actually filled
 __device__ __forceinline__ void up_patch_voxel(int r16, int& dy, int& z) {
   dy = (0xEF80u >> r16) & 1;
   z = (int)((0x2104765437653210ull >> (4 * r16)) & 7ull);
+}
+
+// tap index of shift delta = (dx,dy,dz) in {0,1}^3 inside parity class c = px*4 + py*2 + pz, in the order the host lists a class's taps
+// (capstone_amd/engine.py classes_up: x outermost; a parity-1 axis lists offset +1 before 0) — checked by conv_up_eligible; -1: the
+// class has no such tap
+constexpr int up_tap_index(int c, int delta) {
+  const int px = (c >> 2) & 1, py = (c >> 1) & 1, pz = c & 1, dx = (delta >> 2) & 1, dy = (delta >> 1) & 1, dz = delta & 1;
+  if (dx > px || dy > py || dz > pz) return -1;
+  const int ix = px ? 1 - dx : 0, iy = py ? 1 - dy : 0, iz = pz ? 1 - dz : 0;
+  return (ix * (1 + py) + iy) * (1 + pz) + iz;
 }
 
 template <int VB> struct UpCfg {
@@ -229,6 +242,74 @@ __global__ __launch_bounds__(512) void conv_up_halo_kernel(const ConvKArgs P, in
       }
     };
     using std::integral_constant;
+#if UP_DELTA
+    // "delta-major": the 27 (class, tap) pairs of a transposed conv read only the 8 shifted fragments x[v + delta], delta in {0,1}^3.
+    // Each shifted fragment is read ONCE per 64-byte K chunk and feeds every class of this wave half that has the tap (64 operand
+    // reads per tile and wave instead of 104 - 120); the accumulators of the half's four classes are live together (64 registers).
+    auto do_half = [&](auto c0_, auto c1_, auto c2_, auto c3_) {
+      constexpr int CL[4] = {decltype(c0_)::value, decltype(c1_)::value, decltype(c2_)::value, decltype(c3_)::value};
+      f32x4 acc[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* wc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wc[k] = sW + sWst[CL[k]] * (16 * 128) + wrow;
+#pragma unroll
+      for (int dl = 0; dl < 8; ++dl) {
+        constexpr int dummy = 0; (void)dummy;
+        const int delta = ((((dl >> 2) & 1) * U_HY + ((dl >> 1) & 1)) * U_HZ + (dl & 1)) * 16;
+        const bool used = up_tap_index(CL[0], dl) >= 0 || up_tap_index(CL[1], dl) >= 0 || up_tap_index(CL[2], dl) >= 0 || up_tap_index(CL[3], dl) >= 0;
+        if (!used) continue;
+#pragma unroll
+        for (int kc = 0; kc < CPT; ++kc) {
+          u32x4 xf[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sH + abase[i] + kc * 4 * U_PLANE + delta);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int tp = up_tap_index(CL[k], dl);
+            if (tp < 0) continue;
+            const int ci = tp * CPT + kc;
+            const u32x4 wf = *reinterpret_cast<const u32x4*>(wc[k] + (ci >> 1) * (16 * 128) + (((4 * (ci & 1) + q4) ^ wswz) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mma16<H>(acc[k][i], wf, xf[i]);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const ctseg_conv_class& K = P.cls[CL[k]];
+        const int coff = (K.ox * P.Yo + K.oy) * P.Zo + K.oz;
+        char* ob = P.out + (vb + coff) * P.o_ld * 2;
+        const char* ab = (P.add != nullptr) ? P.add + (vb + coff) * P.add_ld * ASZ : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[k][i][e] + bias[e];
+            if (rv[i]) { wsum[e] += v[e]; wsq[e] += v[e] * v[e]; }
+          }
+          if (rv[i] && ch < P.Cn_store) {
+            if (ab != nullptr) {
+              const char* ap = ab + ((int64_t)ovox[i] * P.add_ld + ch) * ASZ;
+              if (af32) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap); v[0] += a4[0]; v[1] += a4[1]; v[2] += a4[2]; v[3] += a4[3]; }
+              else {
+                const u32x2 w2 = *reinterpret_cast<const u32x2*>(ap);
+                v[0] += h2f<H>(w2[0] & 0xffffu); v[1] += h2f<H>(w2[0] >> 16); v[2] += h2f<H>(w2[1] & 0xffffu); v[3] += h2f<H>(w2[1] >> 16);
+              }
+            }
+            *reinterpret_cast<u32x2*>(ob + ((int64_t)ovox[i] * P.o_ld + ch) * 2) = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
+          }
+        }
+      }
+    };
+    // (same split as below: classes that differ in the z parity share a wave half: their two partial line writes meet in L2)
+    if (half == 0) do_half(integral_constant<int, 7>{}, integral_constant<int, 6>{}, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+    else do_half(integral_constant<int, 5>{}, integral_constant<int, 4>{}, integral_constant<int, 3>{}, integral_constant<int, 2>{});
+#else
     // classes that differ in the z parity write z-neighbouring voxels (two 24-byte rows = 48 contiguous bytes): they run back to back
     // in the same waves so that the two partial writes of a line meet in L2 (15 / 12 taps per wave half instead of 13 / 14)
     if (half == 0) {
@@ -242,6 +323,7 @@ __global__ __launch_bounds__(512) void conv_up_halo_kernel(const ConvKArgs P, in
       do_class(integral_constant<int, 4>{}, 3);
       do_class(integral_constant<int, 2>{}, 2);
     }
+#endif
   };
 
   const int G = gridDim.x;
@@ -290,6 +372,16 @@ bool conv_up_eligible(const ConvKArgs& a, int dtype, int nclass) {
         const int d = (int)(int8_t)((k.taps[j] >> s) & 0xff);
         if (d < 0 || d > 1) return false;
       }
+    // the delta-major schedule addresses a class's taps by (dx,dy,dz): class c = px*4 + py*2 + pz at parity (px,py,pz), taps in the
+    // host's order (up_tap_index)
+    if (k.ox != ((c >> 2) & 1) || k.oy != ((c >> 1) & 1) || k.oz != (c & 1)) return false;
+    for (int dl = 0; dl < 8; ++dl) {
+      const int tp = up_tap_index(c, dl);
+      if (tp < 0) continue;
+      if (tp >= k.ntaps) return false;
+      const int t = k.taps[tp];
+      if ((int)(int8_t)(t & 0xff) != ((dl >> 2) & 1) || (int)(int8_t)((t >> 8) & 0xff) != ((dl >> 1) & 1) || (int)(int8_t)((t >> 16) & 0xff) != (dl & 1)) return false;
+    }
   }
   return taps == 27;
 }
