@@ -415,3 +415,34 @@ def test_loss_module_dict_entries_match_the_oracle(emu, exclude_missing):
             v.backward()
             ref.backward()
         np.testing.assert_allclose(x.grad.numpy(), xr.grad.numpy(), rtol=2e-3, atol=1e-7)
+
+
+
+def test_backward_statistics_come_from_the_producing_pass_where_it_offers_them(emu):
+    """ctseg_conv_desc::bst_* (VERDICT r2 item 2): every InstanceNorm whose output gradient is WRITTEN by a convolution pass gets its
+    backward statistics from that pass's epilogue — no ctseg_instnorm_prelu_bwd_reduce for it — and the gradients are the oracle's
+    (the emulator offers the feature for every pass; the library decides per kernel).  With CTSEG_BST=0 every norm has its reduce."""
+    import os
+    counts = {}
+    for on in ("1", "0"):
+        os.environ["CTSEG_BST"] = on
+        try:
+            ref, net = _pair(3, 1, 10, (4, 8, 16), (2, 2), 2, seed=3)
+            g = torch.Generator().manual_seed(2)
+            x = torch.randn(2, 1, 8, 8, 4, generator=g)
+            gy = torch.randn(2, 10, 8, 8, 4, generator=g)
+            ref(x).backward(gy)
+            eng = net.engine()
+            eng.forward(x)
+            pl = eng.last_plan
+            pl.dlogits.t[..., :10].copy_(gy.permute(0, 2, 3, 4, 1))
+            eng.backward(pl)
+            for (k, p), q in zip(ref.named_parameters(), net.parameters()):
+                np.testing.assert_allclose(eng.store.grad_view(q).numpy(), p.grad.numpy(), err_msg=k, **_tol(k, p.grad.numpy()))
+            counts[on] = (sum(1 for nm, *_ in pl.bwd if nm == "ctseg_instnorm_prelu_bwd_reduce"), [f for _, f in pl.norm_bwd])
+        finally:
+            os.environ.pop("CTSEG_BST", None)
+    n_norms = len(counts["0"][1])
+    assert n_norms >= 8 and counts["0"][0] == n_norms and not any(counts["0"][1])
+    fused = sum(counts["1"][1])
+    assert fused == n_norms and counts["1"][0] == 0, counts      # every norm's gradient is written by a convolution pass here
