@@ -151,9 +151,11 @@ def exchange_rehearsal(batch, steps, precision):
     dev = batch[0].device
     made = False
     if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        import socket
+        with socket.socket() as sk:              # a free port for the one-rank rendezvous
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         made = True
     out = {"backend": dist.get_backend(), "world": dist.get_world_size(), "steps": steps}
     torch.manual_seed(SEED)
