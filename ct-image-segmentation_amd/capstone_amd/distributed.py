@@ -61,6 +61,16 @@ def split_points(ready_marks, sizes, n_total, fractions=(0.6, 0.92)):
     return out
 
 
+class _EventWork:
+    """a Work-like handle over a CUDA event: wait() makes the current stream wait for the communication stream"""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class GradAllReducer:
     def __init__(self, flat_g, n, ready_marks=None, sizes=None, group=None, always=False):
         self.flat_g, self.n, self.group = flat_g, n, group
@@ -68,6 +78,7 @@ class GradAllReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # always=True issues the collectives on a one-rank group too (a one-GPU box can then drive RCCL's stream
         # hand-offs against the two-stream backward; the sums are the identity there)
+        self.always = bool(always)
         self.active = self.world > 1 or (always and dist.is_initialized())
         self.points = split_points(ready_marks, sizes, n) if ready_marks else []
         self.works, self.sent = [], 0
@@ -77,7 +88,7 @@ class GradAllReducer:
     def _launch(self, lo, hi):
         if hi <= lo or not self.active:
             return
-        if self.algo == "direct" and self.world > 1 and hi - lo >= self.world:
+        if self.algo == "direct" and (self.world > 1 or self.always) and hi - lo >= self.world:
             self._launch_direct(lo, hi)
         else:
             self.works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -91,13 +102,39 @@ class GradAllReducer:
         W = self.world
         shard = (hi - lo) // W
         body = self.flat_g[lo:lo + W * shard]
-        recv = torch.empty_like(body)
-        dist.all_to_all_single(recv, body, group=self.group)              # recv[k] = rank k's copy of MY shard
-        mine = recv.view(W, shard).sum(dim=0)
-        self.works.append(dist.all_gather_into_tensor(body, mine, group=self.group, async_op=True))
+        if body.is_cuda:
+            # the three legs run on a communication stream of their own, behind the stream the hook fires on: the
+            # weight gradients queued behind the hook on that stream are not held up by the first leg
+            if getattr(self, "_comm", None) is None:
+                self._comm = torch.cuda.Stream(device=body.device)
+            cur = torch.cuda.current_stream(body.device)
+            self._comm.wait_stream(cur)
+            with torch.cuda.stream(self._comm):
+                recv = torch.empty_like(body)
+                dist.all_to_all_single(recv, body, group=self.group)      # recv[k] = rank k's copy of MY shard
+                mine = self._ordered_sum(recv.view(W, shard))
+                dist.all_gather_into_tensor(body, mine, group=self.group)
+                ev = self._comm.record_event()
+            for t in (recv, mine, body):
+                t.record_stream(self._comm)
+            self.works.append(_EventWork(ev))
+        else:
+            recv = torch.empty_like(body)
+            dist.all_to_all_single(recv, body, group=self.group)          # recv[k] = rank k's copy of MY shard
+            mine = self._ordered_sum(recv.view(W, shard))
+            self.works.append(dist.all_gather_into_tensor(body, mine, group=self.group, async_op=True))
         if lo + W * shard < hi:
             self.works.append(dist.all_reduce(self.flat_g[lo + W * shard:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._keep.append((recv, mine))       # alive until finish(): the collectives read them asynchronously
+
+    @staticmethod
+    def _ordered_sum(parts):
+        """sum over dim 0 in rank order, by explicit adds (not torch.sum, whose reduction order is an implementation detail):
+        every rank computes bit-identical shards"""
+        acc = parts[0].clone()
+        for k in range(1, parts.shape[0]):
+            acc += parts[k]
+        return acc
 
     def points_for(self, plan):
         """split points of THIS plan's backward program (another batch shape, or the 16-wide fallback of the narrow-row layout,

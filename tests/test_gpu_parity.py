@@ -589,19 +589,24 @@ def test_rccl_gradient_exchange_on_one_rank_matches_plain_step(monkeypatch):
     dist.init_process_group(backend="nccl", rank=0, world_size=1)
     try:
         out = []
-        for exchange in (False, True):
+        # exchange: off / the chunked all-reduce / the direct exchange (all-to-all of shards -> rank-ordered sum -> all-gather on a
+        # communication stream of its own, CTSEG_DDP_ALGO=direct): all three are the identity on one rank
+        for exchange in (None, "allreduce", "direct"):
+            if exchange:
+                monkeypatch.setenv("CTSEG_DDP_ALGO", exchange)
             torch.manual_seed(4)
             m = BaseUNet3D(filters=[16, 32, 64], loss_fx=["CrossEntropy"], precision="bf16").to(DEV)
             losses = [float(m.fit_step((images, masks, ind)))]
             if exchange:
                 red = cdist.attach(m, always=True)
-                assert red.active and red.points, "the readiness split must exist so a chunk goes out mid-backward"
+                assert red.active and red.points and red.algo == exchange, "the readiness split must exist so a chunk goes out mid-backward"
             losses += [float(m.fit_step((images, masks, ind))) for _ in range(3)]
             st = m.unet.engine().store
             torch.cuda.synchronize()
             out.append((losses, st.flat_g.clone(), st.flat_p.clone()))
-        assert out[0][0] == out[1][0]
-        assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+        for k in (1, 2):
+            assert out[0][0] == out[k][0]
+            assert torch.equal(out[0][1], out[k][1]) and torch.equal(out[0][2], out[k][2])
     finally:
         dist.destroy_process_group()
 
