@@ -74,3 +74,15 @@ def test_product_has_no_cpu_fallback():
         net(torch.zeros(1, 1, 8, 8, 8))     # CPU tensor: loud failure, not an eager path
     with pytest.raises(nat.NativeError):
         net.model[0].conv.unit0(torch.zeros(1, 1, 8, 8, 8))   # containers never compute
+
+
+def test_pack_block_structs_mirror_the_header():
+    """ctseg_pack_block / ctseg_pack_part (ABI 3, ctseg_pack_weights): field order, array sizes and the struct size of the ctypes
+    mirror follow the header (natural alignment on both sides)."""
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for cname, cls in (("ctseg_pack_part", nat.PackPart), ("ctseg_pack_block", nat.PackBlock)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
+        names = re.findall(r"(?:\*|\s)([A-Za-z_][A-Za-z0-9_]*)(?:\[[A-Za-z_0-9]+\])?\s*[,;]", body)
+        assert names == [f[0] for f in cls._fields_], (cname, names)
+    assert ctypes.sizeof(nat.PackPart) == 32 and ctypes.sizeof(nat.PackBlock) == 8 + 4 * 4 + 8 + 2 * 32 + 4 * nat.MAX_TAPS + 4
+    assert int(re.search(r"#define CTSEG_PACK_LDS_FLOATS (\d+)", open(HEADER).read()).group(1)) == nat.PACK_LDS_FLOATS
