@@ -30,7 +30,13 @@ template <int VB> struct DownCfg {
   static constexpr int NPL = VB / 16, PLANE = HV * 16, HALO = NPL * PLANE;
   static constexpr int CG = VB / 2;
   static constexpr int G = 3;                       // 128-byte K stages per ring slot
-  static constexpr int WRING = 2 * G * DH_KSB;      // 49152
+  static constexpr int NKS_ = ((27 * CG + 31) / 32 + 1) / 2;   // 128-byte K stages of the whole tap list
+  // RES: all K stages of the 64 columns stay in LDS for the whole launch (16 gathered channels: 7 stages = 56 KB beside the 88 KB
+  // halo) instead of being streamed through a two-slot ring every tile.  The ring cost three stage barriers per tile, each a full
+  // vmcnt(0) wait that also drained the register prefetch of the NEXT tile's halo issued just before it: 7.5 us per tile of which
+  // 0.85 are multiplies.
+  static constexpr bool RES = HALO + NKS_ * DH_KSB + 8 * 2 * DH_CN * 4 + 64 * 4 <= 160 * 1024;
+  static constexpr int WRING = RES ? NKS_ * DH_KSB : 2 * G * DH_KSB;      // 57344 resident / 49152 ring
   static constexpr int TOTAL = HALO + WRING + 8 * 2 * DH_CN * 4 + 64 * 4;
 };
 
@@ -247,11 +253,21 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
     first = blockIdx.x; stride = GX; last = total_tiles;
   }
 
+  constexpr bool RES = CF::RES;
   __syncthreads();
   int t = first;
   if (t < last) {
     gload(t);
-    wload(0, 0);
+    if constexpr (RES) {          // every K stage, once
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int rd = 0; rd < 512 / DH_NTHR; ++rd)
+          __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ((int64_t)rd * 32 * kpad) * 2 + (int64_t)ks * 128),
+                                           (lptr_t)(sW + ks * DH_KSB + wave * 1024 + rd * (DH_NTHR * 16)), 16, 0, 0);
+    } else {
+      wload(0, 0);
+    }
     sstore();
   }
   __syncthreads();
@@ -268,13 +284,16 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (RES) { if (tn < last) gload(tn); }        // the next tile's halo has this tile's multiplies AND stores to arrive
 #pragma unroll 1
     for (int rs = 0; rs < NRS; ++rs) {
       const int slot = wstage & 1;
-      if (rs + 1 < NRS) wload(rs + 1, slot ^ 1);
-      else if (tn < last) wload(0, slot ^ 1);
-      if (rs == 0 && tn < last) gload(tn);
-      const char* wb = sW + slot * (RG * DH_KSB) + wrd;
+      if constexpr (!RES) {
+        if (rs + 1 < NRS) wload(rs + 1, slot ^ 1);
+        else if (tn < last) wload(0, slot ^ 1);
+        if (rs == 0 && tn < last) gload(tn);
+      }
+      const char* wb = RES ? sW + rs * (RG * DH_KSB) + wrd : sW + slot * (RG * DH_KSB) + wrd;
 #pragma unroll
       for (int g = 0; g < RG; ++g) {
 #pragma unroll
@@ -300,7 +319,7 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
         }
       }
       ++wstage;
-      __syncthreads();
+      if constexpr (!RES) __syncthreads();
     }
     // ---- epilogue: lane = (voxel (va, vb, pc) of row tile rt, channels (jn0 + j) * 16 + 4 q4 .. + 3) -----------------------
     const int64_t obase = n * out_sample + (int64_t)a0 * G.oa + (int64_t)b0 * G.ob + (int64_t)c0 * G.oc;
@@ -333,7 +352,9 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
       }
     }
     if (tn < last) {
-      sstore();                                              // every wave passed the last ring barrier: halo is free
+      if constexpr (RES) __syncthreads();                    // resident weights: no ring barrier behind the last K stage — every wave
+                                                             // must have left the multiplies before the (single) halo image is overwritten
+      sstore();                                              // (ring: every wave passed the last ring barrier: halo is free)
       __syncthreads();
     }
   }
