@@ -324,10 +324,12 @@ void launch_conv_stem(ConvKArgs& a, hipStream_t st);
 bool conv_halo_x_in_norm_ok(const ConvKArgs& a, int dtype, int nclass);
 bool conv_halo_sw_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_halo_sw_slots(const ConvKArgs& a);
+int conv_halo_sw_bst_slots(const ConvKArgs& a, int nclass);   // 0: this pass cannot take ConvKArgs::bst
 void launch_conv_halo_sw(ConvKArgs& a, int nclass, hipStream_t st);
 // conv_down_halo.hip: stride-2 3x3x3 conv with 16 / 32 gathered channels, 64 columns per workgroup, bf16
 bool conv_down_halo_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_down_halo_slots(const ConvKArgs& a);
+int conv_down_halo_bst_slots(const ConvKArgs& a);   // 0: this pass cannot take ConvKArgs::bst
 void launch_conv_down_halo(ConvKArgs& a, hipStream_t st);
 bool conv_down_r_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_down_r_slots(const ConvKArgs& a);

@@ -35,9 +35,9 @@ template <int VB> struct DownCfg {
   // halo) instead of being streamed through a two-slot ring every tile.  The ring cost three stage barriers per tile, each a full
   // vmcnt(0) wait that also drained the register prefetch of the NEXT tile's halo issued just before it: 7.5 us per tile of which
   // 0.85 are multiplies.
-  static constexpr bool RES = HALO + NKS_ * DH_KSB + 8 * 2 * DH_CN * 4 + 64 * 4 <= 160 * 1024;
+  static constexpr bool RES = HALO + NKS_ * DH_KSB + 8 * 2 * DH_CN * 4 + 64 * 4 + 64 * 4 <= 160 * 1024;
   static constexpr int WRING = RES ? NKS_ * DH_KSB : 2 * G * DH_KSB;      // 57344 resident / 49152 ring
-  static constexpr int TOTAL = HALO + WRING + 8 * 2 * DH_CN * 4 + 64 * 4;
+  static constexpr int TOTAL = HALO + WRING + 8 * 2 * DH_CN * 4 + 64 * 4 + 64 * 4;      // ... + tap table + BST constants
 };
 
 struct DownGeom {
@@ -51,9 +51,15 @@ struct DownGeom {
 
 // R12: the gathered rows are 12 elements wide (24 bytes: the <= 12-channel gradient of the head's transposed conv): staged in
 // 8-byte pieces (3 per voxel) into the same two-plane image; the upper half of every plane-1 slot is zeroed once.
-template <typename H, int VB, bool STATS, bool R12 = false>     // H = 16-bit storage kind (BF16 / F16)
+// BJ >= 0: backward InstanceNorm statistics (ConvKArgs::bst) of the 32 written columns 16 BJ .. 16 BJ + 31 (the half of the
+// transposed conv's input gradient that belongs to the sub-block's output: its last norm consumes it).  A lane keeps the sums of
+// its 8 channels (packed pairs) over both row tiles and every tile of a sample; the y values of a tile are requested at the top of
+// the tile, ahead of the next tile's halo, and have the multiplies to arrive; combined per workgroup at every sample change.
+template <typename H, int VB, bool STATS, bool R12 = false, int BJ = -1>     // H = 16-bit storage kind (BF16 / F16)
 __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs P, const DownGeom G, int total_tiles) {
   static_assert(!R12 || VB == 32, "12-wide rows: 16 gathered channels");
+  constexpr bool BST = BJ >= 0;
+  static_assert(!BST || (VB == 32 && !STATS && (BJ == 0 || BJ == 2)), "backward statistics: the 16-channel gradient pass, one column block, 32 aligned columns");
   using CF = DownCfg<VB>;
   constexpr int TA = CF::TA, HA = CF::HA, NPL = CF::NPL, PLANE = CF::PLANE, CG = CF::CG, RG = CF::G;
   constexpr int FV = HA * 17 * 17, NCH = FV * (R12 ? 3 : NPL), J = (NCH + DH_NTHR - 1) / DH_NTHR;
@@ -69,6 +75,7 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
   char* const sW = smem + CF::HALO;
   float* const sStats = reinterpret_cast<float*>(sW + CF::WRING);
   int* const sTab = reinterpret_cast<int*>(sStats + 8 * 2 * DH_CN);   // per tap: [0,32) halo byte offset, [32,64) XOR flags
+  float* const sBt = reinterpret_cast<float*>(sTab + 64);              // BST: [0,32) rstd, [32,64) -mean * rstd of the sample's channels
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q4 = lane >> 4;
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int ch = col0 + (jn0 + j) * 16 + 4 * q4 + e;
-      bias[j][e] = (P.bias != nullptr && ch < P.Cn) ? P.bias[ch] : 0.f;
+      bias[j][e] = (!BST && P.bias != nullptr && ch < P.Cn) ? P.bias[ch] : 0.f;      // (BST: no bias, host-checked — 16 registers)
     }
   float wsum[NT][4], wsq[NT][4];
 #pragma unroll
@@ -242,6 +249,70 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
     __syncthreads();
   };
 
+  // ---- backward statistics (BST) ---------------------------------------------------------------------------------------
+  f32x2 q1[4], q2[4];
+  float q3 = 0.f;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) { q1[h] = f32x2{0.f, 0.f}; q2[h] = f32x2{0.f, 0.f}; }
+  const int ychunk = (q4 & 1) * 2 + (q4 >> 1);          // the 8-channel chunk (of 32 columns) a lane holds behind the permlane swap
+  const float q_al = BST ? P.bst.alpha[0] : 1.f;
+  const int y_sample_bytes = BST ? (int)(out_sample * P.bst.y_ld * 2) : 0;       // < 2^31 (host-checked)
+  int yoff[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) yoff[rt] = BST ? ((va[rt] * G.oa + vb[rt] * G.ob + pc * G.oc) * P.bst.y_ld + 8 * ychunk) * 2 : 0;
+  u32x4 yq[RT];
+  int bst_n = -1;
+  auto y_issue = [&](int n, int a0, int b0, int c0) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.bst.y) + (int64_t)n * y_sample_bytes, 0, y_sample_bytes, 0x00020000);
+    const int soff = (a0 * G.oa + b0 * G.ob + c0 * G.oc) * P.bst.y_ld * 2;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool rv = (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
+      yq[rt] = __builtin_amdgcn_raw_buffer_load_b128(rs, rv ? yoff[rt] : (int)0x80000000, soff, 0);
+    }
+  };
+  auto bst_consts = [&](int n) {       // (every thread: ends with a barrier)
+    if (tid < 64) {
+      const int c = tid & 31, which = tid >> 5;
+      const float mean = P.bst.mr[((int64_t)n * P.bst.C + c) * 2], rstd = P.bst.mr[((int64_t)n * P.bst.C + c) * 2 + 1];
+      sBt[which * 32 + c] = which == 0 ? rstd : -mean * rstd;
+    }
+    __syncthreads();
+  };
+  auto flush_bst = [&](int n) {        // (every thread: contains barriers)
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float a = q1[h][e], b = q2[h][e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (r16 == 0) {
+          sStats[(wave * 3 + 0) * 32 + ychunk * 8 + 2 * h + e] = a;
+          sStats[(wave * 3 + 1) * 32 + ychunk * 8 + 2 * h + e] = b;
+        }
+        q1[h][e] = 0.f; q2[h][e] = 0.f;
+      }
+    {
+      float c = q3;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+      if (r16 == 0) sStats[(wave * 3 + 2) * 32 + ychunk * 8] = c;      // the slope term: only its total over the channels matters
+      q3 = 0.f;
+    }
+    __syncthreads();
+    if (tid < 96) {
+      const int which = tid >> 5, c = tid & 31;
+      float a = 0.f;
+      if (which < 2 || (c & 7) == 0) {
+#pragma unroll
+        for (int w = 0; w < DH_NTHR / 64; ++w) a += sStats[(w * 3 + which) * 32 + c];
+      }
+      P.bst.part[(((int64_t)n * P.bst.P + blockIdx.x) * 3 + which) * P.bst.ld + c] = a;
+    }
+    __syncthreads();
+  };
+
   const int GX = gridDim.x;
   int first, stride, last;
   if ((GX & 7) == 0) {
@@ -278,6 +349,14 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
     if (STATS && n != stat_n) {
       if (stat_n >= 0) flush_stats(stat_n);
       stat_n = n;
+    }
+    if constexpr (BST) {
+      if (n != bst_n) {
+        if (bst_n >= 0) flush_bst(bst_n);
+        bst_n = n;
+        bst_consts(n);
+      }
+      y_issue(n, a0, b0, c0);
     }
     f32x4 acc[RT][NT];
 #pragma unroll
@@ -327,6 +406,7 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
     for (int rt = 0; rt < RT; ++rt) {
       const bool rv = (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
       const int64_t vox = obase + (int64_t)va[rt] * G.oa + (int64_t)vb[rt] * G.ob + (int64_t)pc * G.oc;
+      u32x2 oc[BST ? NT : 1];        // BST: the packed quads of the row tile, re-dealt into 16-byte chunks below
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int ch = col0 + (jn0 + j) * 16 + 4 * q4;
@@ -336,6 +416,11 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
           v[e] = acc[rt][j][e] + bias[j][e];
           if (STATS && rv) { wsum[j][e] += v[e]; wsq[j][e] += v[e] * v[e]; }
         }
+        if constexpr (BST) {         // (no bias, no addend: host-checked)
+          oc[j] = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
+          continue;
+        }
+        u32x2 o2 = {0u, 0u};
         if (rv && ch < P.Cn_store) {
           if (P.add != nullptr) {
             const char* ap = P.add + (vox * P.add_ld + ch) * ASZ;
@@ -347,7 +432,35 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
           }
           char* op = (P.out2 != nullptr && ch >= P.out2_col0) ? P.out2 + (vox * P.o2_ld + (ch - P.out2_col0)) * 2
                                                                : P.out + (vox * P.o_ld + ch) * 2;
-          *reinterpret_cast<u32x2*>(op) = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
+          o2 = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(op) = o2;
+        }
+      }
+      if constexpr (BST) {
+        // v_permlane16_swap (conv_halo_sw.hip): the lanes of q4 = 0 / 2 get the neighbouring 4 channels of their own 16-column block,
+        // those of q4 = 1 / 3 the ones of the next block: a lane holds 8 consecutive channels = one 16-byte store per 32 columns
+#pragma unroll
+        for (int jp = 0; jp < NT / 2; ++jp) {
+          const auto s0 = __builtin_amdgcn_permlane16_swap(oc[2 * jp][0], oc[2 * jp + 1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(oc[2 * jp][1], oc[2 * jp + 1][1], false, false);
+          const u32x4 o4 = {s0[0], s1[0], s0[1], s1[1]};
+          const int ch = col0 + jp * 32 + ychunk * 8;
+          const bool st = rv && ch < P.Cn_store;
+          if (st) {
+            char* op = (P.out2 != nullptr && ch >= P.out2_col0) ? P.out2 + (vox * P.o2_ld + (ch - P.out2_col0)) * 2
+                                                                 : P.out + (vox * P.o_ld + ch) * 2;
+            *reinterpret_cast<u32x4*>(op) = o4;
+          }
+          if (jp == BJ / 2) {                                  // (g = 0 for the rows the tile does not own)
+            const u32x4 gz = st ? o4 : u32x4{0u, 0u, 0u, 0u};
+            const float* const cb = sBt + ychunk * 8;
+            const f32x4 rs0 = *reinterpret_cast<const f32x4*>(cb), rs1 = *reinterpret_cast<const f32x4*>(cb + 4);
+            const f32x4 nm0 = *reinterpret_cast<const f32x4*>(cb + 32), nm1 = *reinterpret_cast<const f32x4*>(cb + 36);
+            bst_pair_bf16(gz[0], yq[rt][0], f32x2{rs0[0], rs0[1]}, f32x2{nm0[0], nm0[1]}, q_al, q1[0], q2[0], q3);
+            bst_pair_bf16(gz[1], yq[rt][1], f32x2{rs0[2], rs0[3]}, f32x2{nm0[2], nm0[3]}, q_al, q1[1], q2[1], q3);
+            bst_pair_bf16(gz[2], yq[rt][2], f32x2{rs1[0], rs1[1]}, f32x2{nm1[0], nm1[1]}, q_al, q1[2], q2[2], q3);
+            bst_pair_bf16(gz[3], yq[rt][3], f32x2{rs1[2], rs1[3]}, f32x2{nm1[2], nm1[3]}, q_al, q1[3], q2[3], q3);
+          }
         }
       }
     }
@@ -359,6 +472,7 @@ __global__ __launch_bounds__(DH_NTHR) void conv_down_halo_kernel(const ConvKArgs
     }
   }
   if (STATS && stat_n >= 0) flush_stats(stat_n);
+  if constexpr (BST) { if (bst_n >= 0) flush_bst(bst_n); }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -414,6 +528,18 @@ int conv_down_halo_slots(const ConvKArgs& a) {
   return down_grid(a, g);
 }
 
+// ConvKArgs::bst on this pass: the second 32 of its 64 written columns (the sub-block half of the level-0 concat gradient), bf16
+int conv_down_halo_bst_slots(const ConvKArgs& a) {
+  { const char* e = getenv("CTSEG_BST_DOWN"); if (e != nullptr && e[0] == '0') return 0; }   // (A/B switch)
+  // (12-wide gathered rows only: the variant staging 16-byte chunks is at the 256-register line without the sums)
+  if (a.dtype != CTSEG_BF16 || a.g_ld != 12 || a.stats != nullptr || a.bias != nullptr || a.add != nullptr || a.Cn > DH_CN || a.bst.C != 32 || a.bst.col0 != 32 || a.Cn_store < 64) return 0;
+  // 16-byte chunks of 8 channels: the written tensor(s) and y
+  if ((a.bst.y_ld % 8) != 0 || ((uintptr_t)a.bst.y % 16) != 0 || (a.o_ld % 8) != 0 || ((uintptr_t)a.out % 16) != 0 || (a.Cn_store % 8) != 0) return 0;
+  if (a.out2 != nullptr && ((a.o2_ld % 8) != 0 || (a.out2_col0 % 8) != 0 || ((uintptr_t)a.out2 % 16) != 0)) return 0;
+  if ((int64_t)a.Xo * a.Yo * a.Zo * a.bst.y_ld * 2 >= (1ll << 31)) return 0;
+  return conv_down_halo_slots(a);
+}
+
 void launch_conv_down_halo(ConvKArgs& a, hipStream_t st) {
   DownGeom g;
   const int vb = a.Cg * 2;
@@ -424,6 +550,10 @@ void launch_conv_down_halo(ConvKArgs& a, hipStream_t st) {
   const bool stats = a.stats != nullptr;
 #define CTSEG_DH_GO(H, ST, R) hipLaunchKernelGGL((conv_down_halo_kernel<H, 32, ST, R>), grid, blk, 0, st, a, g, total)
   const bool r12 = a.g_ld == 12;
+  if (a.bst.part != nullptr) {        // (bf16, 12-wide gathered rows, no forward statistics, columns 32..63: conv_down_halo_bst_slots)
+    hipLaunchKernelGGL((conv_down_halo_kernel<BF16, 32, false, true, 2>), grid, blk, 0, st, a, g, total);
+    return;
+  }
   if (a.dtype == CTSEG_F16) {
     if (stats) { if (r12) CTSEG_DH_GO(F16, true, true); else CTSEG_DH_GO(F16, true, false); }
     else { if (r12) CTSEG_DH_GO(F16, false, true); else CTSEG_DH_GO(F16, false, false); }

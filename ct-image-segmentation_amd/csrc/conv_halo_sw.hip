@@ -23,7 +23,7 @@
 #define SW_FULL_WAIT 0
 #endif
 #ifndef SW_ABL
-#define SW_ABL 0     // timing-only ablation: 1 no MFMAs, 2 no LDS operand reads, 4 no weight stream, 8 no output stores (and no addend loads), 16 no halo loads, 32 no addend loads
+#define SW_ABL 0     // timing-only ablation: 1 no MFMAs, 2 no LDS operand reads, 4 no weight stream, 8 no output stores (and no addend loads), 16 no halo loads, 32 no addend loads, 64 BST without the y loads, 128 BST without its arithmetic
 #endif
 
 namespace ctseg {
@@ -49,7 +49,7 @@ template <int VB, bool UP> struct SwCfg {
   static constexpr int G = DENSE ? 2 : 3;               // taps per ring stage
   static constexpr int NSTAGE = (27 + G - 1) / G;
   static constexpr int WRING = 2 * G * SW_TAPB;
-  static constexpr int TOTAL = HALO + WRING + 8 * 2 * CN * 4 + 128 * 4;
+  static constexpr int TOTAL = HALO + WRING + 8 * 3 * CN * 4 + 128 * 4 + 2 * CN * 4;     // ... + partial sums of the waves + tap tables + BST constants
   static_assert(TOTAL <= 160 * 1024, "LDS");
   __host__ __device__ static constexpr int slot(int ha, int hb, int hc) { return ((ha - O) * LB + (hb - O)) * 10 + hc; }
 };
@@ -67,8 +67,15 @@ __device__ __forceinline__ void sw_patch_voxel(int r16, int& db, int& c) {
   c = (int)((0x2104765437653210ull >> (4 * r16)) & 7ull);
 }
 
-template <typename H, int VB, bool UP, bool STATS>     // H = 16-bit storage kind (BF16 / F16)
+// BST: backward InstanceNorm statistics of the written gradient (ConvKArgs::bst) on the input-gradient passes (8-class 128 -> 32,
+// single-class 64 -> 64).  After the v_permlane16_swap of the store a lane holds 16-byte chunks (8 consecutive channels) of one
+// voxel: the matching y chunks are requested one class ahead, beside the addend of that class (8 classes), or at the top of the
+// tile's epilogue (one class: they arrive under the bias / addend / pack arithmetic), and the lane keeps the sums of its 8 or 16
+// channels (packed pairs) over all classes and tiles of a sample; combined per workgroup at every sample change, like the forward
+// statistics.
+template <typename H, int VB, bool UP, bool STATS, bool BST = false>     // H = 16-bit storage kind (BF16 / F16)
 __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P, const SwGeom G, int total_tiles) {
+  static_assert(!BST || (!STATS && ((UP && VB == 256) || (!UP && VB == 128))), "backward statistics: the input-gradient passes this kernel takes");
   using CF = SwCfg<VB, UP>;
   constexpr int TA = CF::TA, NPL = CF::NPL, PLANE = CF::PLANE, CN = CF::CN, NT = CF::NT, RT = CF::RT, KS = CF::KS;
   constexpr int SW_G = CF::G, SW_NSTAGE = CF::NSTAGE;
@@ -80,7 +87,8 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
   char* const sH = smem;
   char* const sW = smem + CF::HALO;
   float* const sStats = reinterpret_cast<float*>(sW + CF::WRING);
-  int* const sTab = reinterpret_cast<int*>(sStats + 8 * 2 * CN);       // [0,32) halo delta, [32,64) weight offset, [64,96) kpad, [96,128) class | last<<8
+  int* const sTab = reinterpret_cast<int*>(sStats + 8 * 3 * CN);       // [0,32) halo delta, [32,64) weight offset, [64,96) kpad, [96,128) class | last<<8
+  float* const sBt = reinterpret_cast<float*>(sTab + 128);             // BST: [0,CN) rstd, [CN,2 CN) -mean * rstd of the sample's channels
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q4 = lane >> 4;
@@ -102,17 +110,30 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
   }
 
   // ---- halo staging slots: per-thread constants, only a scalar tile base changes ---------------------------------------
-  int g_byte[J], g_habc[J], g_lds[J];
+  // LEAN (the BST variant, which sits at the 256-register line): only the packed halo coordinates stay in registers; the source and
+  // LDS offsets (2 x J registers) are recomputed from them for every tile (a dozen multiply-adds per slot against a 40 us tile).
+  // The channel plane of a slot does not depend on j there (512 threads = 64 voxel octets x 16 planes ... SW_NTHR / 8 % NPL == 0).
+  constexpr bool LEAN = BST;
+  static_assert(!LEAN || (SW_NTHR / 8) % NPL == 0, "lean staging: the plane of a slot must not depend on j");
+  int g_byte[LEAN ? 1 : J], g_habc[J], g_lds[LEAN ? 1 : J];
+  const int pl0 = (tid >> 3) % NPL;
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const int idx = tid + j * SW_NTHR;
     const int pl = (idx >> 3) % NPL, fv = (idx / (8 * NPL)) * 8 + (idx & 7);
     const int fa = fv / (FB * FB), rem = fv - fa * (FB * FB), fb = rem / FB, fc = rem - fb * FB;
     const int ha = fa + O, hb = fb + O, hc = fc + O;                   // halo coordinates, tile origin = (1,1,1)
-    g_byte[j] = (((ha - 1) * G.ia + (hb - 1) * G.ib + (hc - 1) * G.ic) * P.g_ld + pl * 8) * 2;
     g_habc[j] = (fv < FV) ? (ha | (hb << 8) | (hc << 16)) : 0x7f7f7f;  // sentinel fails every bounds test
-    g_lds[j] = pl * PLANE + CF::slot(ha, hb, hc) * 16;
+    if constexpr (!LEAN) {
+      g_byte[j] = (((ha - 1) * G.ia + (hb - 1) * G.ib + (hc - 1) * G.ic) * P.g_ld + pl * 8) * 2;
+      g_lds[j] = pl * PLANE + CF::slot(ha, hb, hc) * 16;
+    }
   }
+  auto lean_habc = [&](int j, int& ha, int& hb, int& hc) {     // (opaque to the optimiser: otherwise it hoists the offsets back into registers)
+    int h = g_habc[j];
+    asm volatile("" : "+v"(h));
+    ha = h & 0xff; hb = (h >> 8) & 0xff; hc = h >> 16;
+  };
   auto tile_origin = [&](int t, int& n, int& a0, int& b0, int& c0) {
     n = t / G.tiles;
     int r = t - n * G.tiles;
@@ -131,15 +152,32 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
     for (int j = 0; j < J; ++j) {
       const int ai = a0 - 1 + (g_habc[j] & 0xff), bi = b0 - 1 + ((g_habc[j] >> 8) & 0xff), ci = c0 - 1 + (g_habc[j] >> 16);
       u32x4 v = {0u, 0u, 0u, 0u};
+      int gb;
+      if constexpr (LEAN) {
+        int ha, hb, hc;
+        lean_habc(j, ha, hb, hc);
+        gb = (((ha - 1) * G.ia + (hb - 1) * G.ib + (hc - 1) * G.ic) * P.g_ld + pl0 * 8) * 2;
+      } else {
+        gb = g_byte[j];
+      }
       if (!(SW_ABL & 16) && (unsigned)ai < (unsigned)G.da && (unsigned)bi < (unsigned)G.db && (unsigned)ci < (unsigned)G.dc)
-        v = *reinterpret_cast<const u32x4*>(base + g_byte[j]);
+        v = *reinterpret_cast<const u32x4*>(base + gb);
       rh[j] = v;
     }
   };
   auto sstore = [&]() {
 #pragma unroll
-    for (int j = 0; j < J; ++j)
-      if ((g_habc[j] & 0xff) != 0x7f) *reinterpret_cast<u32x4*>(sH + g_lds[j]) = rh[j];
+    for (int j = 0; j < J; ++j) {
+      int gl;
+      if constexpr (LEAN) {
+        int ha, hb, hc;
+        lean_habc(j, ha, hb, hc);
+        gl = pl0 * PLANE + CF::slot(ha, hb, hc) * 16;
+      } else {
+        gl = g_lds[j];
+      }
+      if ((g_habc[j] & 0xff) != 0x7f) *reinterpret_cast<u32x4*>(sH + gl) = rh[j];
+    }
   };
 
   // ---- weight stream: thread = one 16-byte chunk of a tap's [CN][CG] block, lane-linear LDS image, source-side swizzle -------
@@ -180,7 +218,7 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bias[j][e] = (P.bias != nullptr) ? P.bias[j * 16 + 4 * q4 + e] : 0.f;
+    for (int e = 0; e < 4; ++e) bias[j][e] = (!BST && P.bias != nullptr) ? P.bias[j * 16 + 4 * q4 + e] : 0.f;     // (BST: no bias, host-checked)
 
   float wsum[NT][4], wsq[NT][4];
 #pragma unroll
@@ -239,22 +277,104 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
     aoff[rt] = (vox * P.add_ld + 4 * q4) * ASZ;
   }
   u32x2 apre[RT][NT];
+  // ---- backward statistics (BST) --------------------------------------------------------------------------------------------
+  constexpr int NQ = NT / 2;                            // 16-byte chunks (of 32 channels each ... chunk jp = channels 32 jp + 8 ychunk ..) per lane
+  f32x2 q1[NQ][4], q2[NQ][4];
+  float q3 = 0.f;
+#pragma unroll
+  for (int jp = 0; jp < NQ; ++jp)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { q1[jp][h] = f32x2{0.f, 0.f}; q2[jp][h] = f32x2{0.f, 0.f}; }
+  const float q_al = BST ? P.bst.alpha[0] : 1.f;
+  const int ychunk = (q4 & 1) * 2 + (q4 >> 1);          // the 8-channel chunk a lane holds behind the permlane swap
+  const int y_sample_bytes = BST ? (int)(out_sample * P.bst.y_ld * 2) : 0;     // < 2^31 (host-checked)
+  int yoffc[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) yoffc[rt] = BST ? ((va[rt] * G.oa + vb[rt] * G.ob + pc * G.oc) * P.bst.y_ld + ychunk * 8) * 2 : 0;
+  u32x4 ypre[RT];
+  int bst_n = -1;
+  auto bst_consts = [&](int n) {       // (every thread: ends with a barrier)
+    if (tid < 2 * CN) {
+      const int c = tid % CN, which = tid / CN;
+      const float mean = P.bst.mr[((int64_t)n * P.bst.C + c) * 2], rstd = P.bst.mr[((int64_t)n * P.bst.C + c) * 2 + 1];
+      sBt[which * CN + c] = which == 0 ? rstd : -mean * rstd;
+    }
+    __syncthreads();
+  };
+  auto bst_chunk = [&](int jp, const u32x4& gz, const u32x4& yv) {      // 8 channels of one voxel: stored gradient, forward y
+    if (SW_ABL & 128) { q3 += __uint_as_float(gz[0] ^ yv[3]); return; }
+    const float* const cb = sBt + jp * 32 + ychunk * 8;
+    const f32x4 rs0 = *reinterpret_cast<const f32x4*>(cb), rs1 = *reinterpret_cast<const f32x4*>(cb + 4);
+    const f32x4 nm0 = *reinterpret_cast<const f32x4*>(cb + CN), nm1 = *reinterpret_cast<const f32x4*>(cb + CN + 4);
+    bst_pair_bf16(gz[0], yv[0], f32x2{rs0[0], rs0[1]}, f32x2{nm0[0], nm0[1]}, q_al, q1[jp][0], q2[jp][0], q3);
+    bst_pair_bf16(gz[1], yv[1], f32x2{rs0[2], rs0[3]}, f32x2{nm0[2], nm0[3]}, q_al, q1[jp][1], q2[jp][1], q3);
+    bst_pair_bf16(gz[2], yv[2], f32x2{rs1[0], rs1[1]}, f32x2{nm1[0], nm1[1]}, q_al, q1[jp][2], q2[jp][2], q3);
+    bst_pair_bf16(gz[3], yv[3], f32x2{rs1[2], rs1[3]}, f32x2{nm1[2], nm1[3]}, q_al, q1[jp][3], q2[jp][3], q3);
+  };
+  auto flush_bst = [&](int n) {        // (every thread: contains barriers)
+#pragma unroll
+    for (int jp = 0; jp < NQ; ++jp)
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float a = q1[jp][h][e], b = q2[jp][h][e];
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+          if (r16 == 0) {
+            sStats[(wave * 3 + 0) * CN + jp * 32 + ychunk * 8 + 2 * h + e] = a;
+            sStats[(wave * 3 + 1) * CN + jp * 32 + ychunk * 8 + 2 * h + e] = b;
+          }
+          q1[jp][h][e] = 0.f; q2[jp][h][e] = 0.f;
+        }
+    {
+      float c = q3;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+      if (r16 == 0) sStats[(wave * 3 + 2) * CN + ychunk * 8] = c;      // the slope term: only its total over the channels matters
+      q3 = 0.f;
+    }
+    __syncthreads();
+    if (tid < 3 * CN) {
+      const int which = tid / CN, c = tid % CN;
+      float a = 0.f;
+      if (which < 2 || ((c & 7) == 0 && c < 32)) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) a += sStats[(w * 3 + which) * CN + c];
+      }
+      P.bst.part[(((int64_t)n * P.bst.P + blockIdx.x) * 3 + which) * P.bst.ld + c] = a;
+    }
+    __syncthreads();
+  };
   int pend = 0;                                         // vector-memory operations issued since this stage's weight DMA (wave-uniform)
   auto class_base = [&](int cls, int a0, int b0, int c0) -> int {
     const ctseg_conv_class& K = P.cls[cls];
     return a0 * G.oa + b0 * G.ob + c0 * G.oc + (K.ox * P.Yo + K.oy) * P.Zo + K.oz;
   };
   auto add_issue = [&](int cls, int n, int a0, int b0, int c0) {        // cls < 0: nothing to fetch (same operation count)
-    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.add) + (int64_t)n * add_sample_bytes, 0, add_sample_bytes, 0x00020000);
-    const int soff = cls >= 0 ? class_base(cls, a0, b0, c0) * P.add_ld * ASZ : 0;
+    const int cb = cls >= 0 ? class_base(cls, a0, b0, c0) : 0;
+    if (apf) {
+      const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.add) + (int64_t)n * add_sample_bytes, 0, add_sample_bytes, 0x00020000);
+      const int soff = cb * P.add_ld * ASZ;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const bool rv = cls >= 0 && (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
+      for (int rt = 0; rt < RT; ++rt) {
+        const bool rv = cls >= 0 && (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        apre[rt][j] = (SW_ABL & 32) ? u32x2{0u, 0u} : __builtin_amdgcn_raw_buffer_load_b64(ars, rv ? aoff[rt] + j * 16 * ASZ : (int)0x80000000, soff, 0);
+        for (int j = 0; j < NT; ++j)
+          apre[rt][j] = (SW_ABL & 32) ? u32x2{0u, 0u} : __builtin_amdgcn_raw_buffer_load_b64(ars, rv ? aoff[rt] + j * 16 * ASZ : (int)0x80000000, soff, 0);
+      }
+      pend += RT * NT;
     }
-    pend += RT * NT;
+    if constexpr (BST) {             // the y chunks of the class's voxels
+      const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.bst.y) + (int64_t)n * y_sample_bytes, 0, y_sample_bytes, 0x00020000);
+      const int soff = cb * P.bst.y_ld * 2;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const bool rv = cls >= 0 && (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
+        ypre[rt] = (SW_ABL & 64) ? u32x4{1u, 2u, 3u, (uint32_t)soff} : __builtin_amdgcn_raw_buffer_load_b128(yrs, rv ? yoffc[rt] : (int)0x80000000, soff, 0);
+      }
+      pend += RT;
+    }
   };
   auto epilogue = [&](int cls, int next_cls, int n, int a0, int b0, int c0) {
     const int cb = class_base(cls, a0, b0, c0);
@@ -306,15 +426,22 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
         // v_mov into the first data register right behind the store — a few 16-bit elements per launch came out as garbage.
         // Keeping the registers live across two wait states closes the window.
         asm volatile("s_nop 1" ::"v"(o4));
+        if constexpr (BST) bst_chunk(jp, rv ? o4 : u32x4{0u, 0u, 0u, 0u}, ypre[rt]);   // (NT = 2: one chunk per row tile; g = 0 for voxels the tile does not own)
       }
     }
     pend += RT * NT / 2;
-    if (apf) add_issue(next_cls, n, a0, b0, c0);
+    if (apf || BST) add_issue(next_cls, n, a0, b0, c0);
   };
   // stage barrier: the next stage's weight DMA (issued first in this stage) has landed, later stores / addend loads may still fly
   auto stage_barrier = [&]() {
-    constexpr int E1 = RT * NT / 2, E2 = RT * NT / 2 + RT * NT;      // one epilogue without / with the next addend request
+    // one epilogue without / with the next addend request (BST: + the y chunks, with or without an addend)
+    constexpr int YL = BST ? RT : 0, E1 = RT * NT / 2 + YL, E2 = RT * NT / 2 + RT * NT + YL;
+    constexpr int T1 = YL, T2 = RT * NT + YL;                        // BST: the first class's request at the top of a tile (no stores)
     if (SW_FULL_WAIT || pend == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (BST && pend == T1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(T1) : "memory");
+    else if (BST && pend == T2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(T2) : "memory");
+    else if (BST && pend == T1 + E1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(T1 + E1) : "memory");
+    else if (BST && pend == T2 + E2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(T2 + E2) : "memory");
     else if (pend == E1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(E1) : "memory");
     else if (pend == 2 * E1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * E1) : "memory");
     else if (pend == E2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(E2) : "memory");
@@ -359,6 +486,51 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
     }
   };
 
+  // single-class pass with BST: 16-byte chunks as above (buffer stores with a per-sample descriptor), the y chunks requested first
+  auto epilogue_plain_bst = [&](int n, int a0, int b0, int c0) {
+    const ctseg_conv_class& K = P.cls[0];
+    const int cb = a0 * G.oa + b0 * G.ob + c0 * G.oc + (K.ox * P.Yo + K.oy) * P.Zo + K.oz;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(P.out + (int64_t)n * out_sample_bytes, 0, out_sample_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.bst.y) + (int64_t)n * y_sample_bytes, 0, y_sample_bytes, 0x00020000);
+    u32x4 yq[RT][NQ];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool rv = (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
+#pragma unroll
+      for (int jp = 0; jp < NQ; ++jp) yq[rt][jp] = __builtin_amdgcn_raw_buffer_load_b128(yrs, rv ? yoffc[rt] + jp * 64 : (int)0x80000000, cb * P.bst.y_ld * 2, 0);
+    }
+    const int cbq = ychunk * 16;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool rv = (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
+      u32x2 o2[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[rt][j][e];
+        if (P.add != nullptr && rv) {
+          const char* ap = P.add + (int64_t)n * add_sample_bytes + (int64_t)cb * P.add_ld * ASZ + aoff[rt] + j * 16 * ASZ;
+          if (af32) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap); v[0] += a4[0]; v[1] += a4[1]; v[2] += a4[2]; v[3] += a4[3]; }
+          else {
+            const u32x2 w2 = *reinterpret_cast<const u32x2*>(ap);
+            v[0] += h2f<H>(w2[0] & 0xffffu); v[1] += h2f<H>(w2[0] >> 16); v[2] += h2f<H>(w2[1] & 0xffffu); v[3] += h2f<H>(w2[1] >> 16);
+          }
+        }
+        o2[j] = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
+      }
+#pragma unroll
+      for (int jp = 0; jp < NQ; ++jp) {
+        const auto s0 = __builtin_amdgcn_permlane16_swap(o2[2 * jp][0], o2[2 * jp + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(o2[2 * jp][1], o2[2 * jp + 1][1], false, false);
+        const u32x4 o4 = {s0[0], s1[0], s0[1], s1[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(o4, ors, rv ? ooff[rt] - 4 * q4 * 2 + jp * 64 + cbq : (int)0x80000000, cb * P.o_ld * 2, 0);
+        asm volatile("s_nop 1" ::"v"(o4));            // (the store-data hazard of epilogue() above)
+        bst_chunk(jp, rv ? o4 : u32x4{0u, 0u, 0u, 0u}, yq[rt][jp]);
+      }
+    }
+  };
+
   // tile sequence: each XCD owns a contiguous range of tiles (neighbouring halos share that XCD's L2)
   const int GX = gridDim.x;
   int first, stride, last;
@@ -387,6 +559,13 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
       if (stat_n >= 0) flush_stats(stat_n);
       stat_n = n;
     }
+    if constexpr (BST) {
+      if (n != bst_n) {
+        if (bst_n >= 0) flush_bst(bst_n);
+        bst_n = n;
+        bst_consts(n);
+      }
+    }
     zero_acc();
 #pragma unroll 1
     for (int s = 0; s < SW_NSTAGE; ++s) {
@@ -394,7 +573,7 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
       if (s + 1 < SW_NSTAGE) wload(s + 1, slot ^ 1);
       else if (tn < last) wload(0, slot ^ 1);        // first stage of the next tile
       if (s == 0 && tn < last) gload(tn);            // next halo rides in registers until this tile is done
-      if (apf && s == 0) add_issue(sTab[96] & 255, n, a0, b0, c0);
+      if ((apf || BST) && s == 0) add_issue(sTab[96] & 255, n, a0, b0, c0);
       const char* wb = sW + slot * (SW_G * SW_TAPB) + wrd;
 #pragma unroll
       for (int g = 0; g < SW_G; ++g) {
@@ -430,7 +609,8 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
       if constexpr (UP) stage_barrier();             // next stage's DMA landed, this slot is free
       else __syncthreads();
     }
-    if constexpr (!UP) epilogue_plain(0, n, a0, b0, c0);
+    if constexpr (!UP && BST) epilogue_plain_bst(n, a0, b0, c0);
+    else if constexpr (!UP) epilogue_plain(0, n, a0, b0, c0);
     if (tn < last) {
       // every wave passed the last stage barrier => nobody reads the halo any more
       sstore();
@@ -438,6 +618,7 @@ __global__ __launch_bounds__(SW_NTHR) void conv_halo_sw_kernel(const ConvKArgs P
     }
   }
   if (STATS && stat_n >= 0) flush_stats(stat_n);
+  if constexpr (BST) { if (bst_n >= 0) flush_bst(bst_n); }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -505,6 +686,17 @@ int conv_halo_sw_slots(const ConvKArgs& a) {
   return sw_grid(a, g);
 }
 
+// ConvKArgs::bst on this pass: the 8-class 128 -> 32 and the single-class 64 -> 64 input gradients in bf16, all written channels
+int conv_halo_sw_bst_slots(const ConvKArgs& a, int nclass) {
+  { const char* e = getenv("CTSEG_BST_SW"); if (e != nullptr && (e[0] == '0' || (e[0] == '8' && nclass != 8) || (e[0] == '1' && nclass != 1))) return 0; }   // (A/B switch)
+  if (a.dtype != CTSEG_BF16 || a.stats != nullptr || a.bias != nullptr) return 0;
+  if (!((nclass == 8 && a.Cg == 128) || (nclass == 1 && a.Cg == 64))) return 0;
+  if (a.bst.C != a.Cn || a.bst.col0 != 0 || a.Cn_store != a.Cn || (a.o_ld % 8) != 0 || ((uintptr_t)a.out % 16) != 0) return 0;
+  if ((a.bst.y_ld % 8) != 0 || ((uintptr_t)a.bst.y % 16) != 0) return 0;
+  if ((int64_t)a.Xo * a.Yo * a.Zo * a.bst.y_ld * 2 >= (1ll << 31) || (int64_t)a.Xo * a.Yo * a.Zo * a.o_ld * 2 >= (1ll << 31)) return 0;
+  return conv_halo_sw_slots(a);
+}
+
 void launch_conv_halo_sw(ConvKArgs& a, int nclass, hipStream_t st) {
   SwGeom g;
   const int vb = a.Cg * 2;
@@ -513,6 +705,11 @@ void launch_conv_halo_sw(ConvKArgs& a, int nclass, hipStream_t st) {
   const int total = g.tiles * a.N;
   const dim3 grid((unsigned)sw_grid(a, g)), blk(SW_NTHR);
   const bool up = nclass == 8, stats = a.stats != nullptr;
+  if (a.bst.part != nullptr) {        // (conv_halo_sw_bst_slots: bf16, 8 classes, 128 -> 32, no forward statistics)
+    if (up) hipLaunchKernelGGL((conv_halo_sw_kernel<BF16, 256, true, false, true>), grid, blk, 0, st, a, g, total);
+    else hipLaunchKernelGGL((conv_halo_sw_kernel<BF16, 128, false, false, true>), grid, blk, 0, st, a, g, total);
+    return;
+  }
 #define CTSEG_SW_LAUNCH(VB, UP, ST)                                                                                      \
   do {                                                                                                                  \
     if (a.dtype == CTSEG_F16) hipLaunchKernelGGL((conv_halo_sw_kernel<F16, VB, UP, ST>), grid, blk, 0, st, a, g, total); \

@@ -50,12 +50,10 @@ def test_no_wide_store_hazard_in_the_shipped_library():
 
 # scratch bytes per lane the round-3 tree is known to carry (demangled prefix -> bytes): these may shrink, never grow
 _KNOWN_SCRATCH = {
-    "void ctseg::conv_down_halo_kernel<ctseg::F16, 32, true, false>": 100,
-    "void ctseg::conv_down_halo_kernel<ctseg::BF16, 32, true, false>": 84,
-    "void ctseg::conv_down_halo_kernel<ctseg::F16, 32, true, true>": 56,
-    "void ctseg::conv_down_halo_kernel<ctseg::BF16, 32, true, true>": 52,
-    "void ctseg::conv_halo_sw_kernel<ctseg::F16, 128, false, true>": 40,
-    "void ctseg::conv_halo_sw_kernel<ctseg::BF16, 128, false, true>": 36,
+    "void ctseg::conv_down_halo_kernel<ctseg::F16, 32, true, false, -1>": 28,
+    "void ctseg::conv_down_halo_kernel<ctseg::BF16, 32, true, false, -1>": 24,
+    "void ctseg::conv_halo_sw_kernel<ctseg::F16, 128, false, true, false>": 40,
+    "void ctseg::conv_halo_sw_kernel<ctseg::BF16, 128, false, true, false>": 36,
     "void ctseg::conv_wgrad_head_kernel<4, 4>": 24,
     "void ctseg::conv_wgrad_head_kernel<4, 3>": 20,
 }
