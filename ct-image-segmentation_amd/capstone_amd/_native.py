@@ -97,7 +97,9 @@ class WgradDesc(_SizedDesc):
                 ("Cg", C.c_int32), ("Cn", C.c_int32), ("g_ld", C.c_int32), ("d_ld", C.c_int32), ("sin", C.c_int32),
                 ("ntaps", C.c_int32), ("taps", C.c_int32 * MAX_TAPS), ("splits", C.c_int32),
                 ("kpad_w", C.c_int32), ("cn_pad", C.c_int32),
-                ("in_mean_rstd", C.c_void_p), ("in_alpha", C.c_void_p), ("in_norm_C", C.c_int32)]
+                ("in_mean_rstd", C.c_void_p), ("in_alpha", C.c_void_p), ("in_norm_C", C.c_int32),
+                ("dyn_col0", C.c_int32), ("dyn_g", C.c_void_p), ("dyn_y", C.c_void_p), ("dyn_g_ld", C.c_int32), ("dyn_y_ld", C.c_int32),
+                ("dyn_mean_rstd", C.c_void_p), ("dyn_alpha", C.c_void_p), ("dyn_sums", C.c_void_p)]
 
 
 _i32, _i64, _f32, _f64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
@@ -113,6 +115,7 @@ _SIGS = {
     "ctseg_conv_in_norm_ok": (C.c_int, [C.POINTER(ConvDesc)]),
     "ctseg_conv_bwd_stats_slots": (C.c_int, [C.POINTER(ConvDesc)]),
     "ctseg_wgrad_in_norm_ok": (C.c_int, [C.POINTER(WgradDesc)]),
+    "ctseg_wgrad_dy_norm_ok": (C.c_int, [C.POINTER(WgradDesc)]),
     "ctseg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "ctseg_wgrad_tile_cols": (C.c_int, [_i32]),
     "ctseg_conv_wgrad_slabs": (C.c_int, [C.POINTER(WgradDesc)]),

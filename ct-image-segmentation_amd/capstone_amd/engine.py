@@ -453,18 +453,42 @@ class GemmLayer:
         plan.emit("ctseg_conv_igemm", d, keep=(dy, out, add, marked.bst[1] if marked is not None else None, bst.y if marked is not None else None))
         return out
 
-    def emit_wgrad(self, x, dy, bias_done=False):
-        """weight + bias gradients straight into the flat gradient buffer (deterministic split-K)."""
+    def wgrad_dyn_ok(self, x, dy_lo, y):
+        """can this layer's weight-gradient pass form the upper columns of dY on load (ctseg_wgrad_desc::dyn_*)?  ``dy_lo``: the
+        gradient of the lower column block, ``y``: the forward output of the upper one (the norm's input)"""
+        if self.transposed or self.Cn != dy_lo.C + y.C or os.environ.get("CTSEG_WGRAD_DYN", "1") == "0":
+            return False
+        d = nat.WgradDesc()
+        d.in_, d.dy, d.dtype = x.ptr(), dy_lo.ptr(), self.plan.dt
+        d.N, d.Xi, d.Yi, d.Zi = x.dims
+        d.Xr, d.Yr, d.Zr = y.dims[1:]
+        d.Cg, d.Cn, d.g_ld, d.d_ld, d.sin, d.ntaps = self.cg, self.Cn, x.ld, dy_lo.ld, self.s, self.T
+        for j, (_, off) in enumerate(self.wg_taps):
+            d.taps[j] = off
+        d.splits, d.kpad_w, d.cn_pad = 1, rup(self.T * self.cg + 1, 128), rup(self.Cn, nat.lib().ctseg_wgrad_tile_cols(self.Cn))
+        d.dyn_col0, d.dyn_g, d.dyn_y = dy_lo.C, y.ptr(), y.ptr()
+        d.dyn_g_ld, d.dyn_y_ld = rup(y.C, nat.epc(self.plan.dt)), y.ld
+        return nat.query("ctseg_wgrad_dy_norm_ok", d) == 1
+
+    def emit_wgrad(self, x, dy, bias_done=False, dyn=None):
+        """weight + bias gradients straight into the flat gradient buffer (deterministic split-K).  ``dyn`` = (g, norm, sums): ``dy``
+        holds the lower column block only; the upper one is the InstanceNorm + PReLU backward of ``g`` through ``norm``, formed on
+        load by the pass (wgrad_dyn_ok)."""
         plan, st = self.plan, self.plan.store
         lib = nat.lib()
-        if not self.transposed:
+        if dyn is not None:
+            assert not self.transposed
+            gathered, dyy, cg, A, cn = x, dy, self.cg, self.cin, self.Cn
+            rowgrid, sin = dyn[1].y.dims[1:], self.s
+            assert dy.C + dyn[0].C == cn and dyn[1].y.C == dyn[0].C
+        elif not self.transposed:
             gathered, dyy, cg, A, cn = x, dy, self.cg, self.cin, self.Cn
             rowgrid, sin = dy.dims[1:], self.s
         else:
             assert self.s == 2, "stride-1 transposed conv wgrad not implemented"
             gathered, dyy, cg, A, cn = dy, x, self.cgd, self.Cn, self.cin
             rowgrid, sin = x.dims[1:], 2
-        assert dyy.C == cn, (self.name, dyy.C, cn)
+        assert dyn is not None or dyy.C == cn, (self.name, dyy.C, cn)
         N = gathered.dims[0]
         rows = rowgrid[0] * rowgrid[1] * rowgrid[2]
         bnw = lib.ctseg_wgrad_tile_cols(cn)
@@ -488,6 +512,11 @@ class GemmLayer:
         for j, (_, off) in enumerate(self.wg_taps):
             d.taps[j] = off
         d.splits, d.kpad_w, d.cn_pad = splits, kpad_w, cn_pad
+        if dyn is not None:
+            g_up, norm, sums = dyn
+            d.dyn_col0, d.dyn_g, d.dyn_g_ld, d.dyn_y, d.dyn_y_ld = dy.C, g_up.ptr(), g_up.ld, norm.y.ptr(), norm.y.ld
+            d.dyn_mean_rstd, d.dyn_alpha, d.dyn_sums = norm.mr.data_ptr(), st.p_ptr(norm.alpha), sums.data_ptr()
+            assert nat.query("ctseg_wgrad_dy_norm_ok", d) == 1, self.name
         pend = getattr(gathered, "pending_norm", None)
         if pend is not None:
             assert not self.transposed
@@ -503,7 +532,7 @@ class GemmLayer:
         assert nslabs > 0
         ws = torch.zeros(nslabs * kpad_w * cn_pad, dtype=torch.float32, device=plan.device)
         d.ws = ws.data_ptr()
-        plan.emit("ctseg_conv_wgrad", d, keep=(gathered, dyy, ws))
+        plan.emit("ctseg_conv_wgrad", d, keep=(gathered, dyy, ws, dyn))
         if not self.transposed:
             col0 = 0
             for w, b, cout in self.parts:

@@ -285,9 +285,23 @@ struct StemWgradArgs {
   float* ws;
   int N, Xi, Yi, Zi, Xr, Yr, Zr, d_ld, kpad_w, cn_pad;
   StemGeom G;
+  // DYN (ctseg_wgrad_desc::dyn_*): the upper half of the dY columns is formed on load from (g, y) of the norm behind it
+  const char* dyn_g;
+  const char* dyn_y;
+  const float* dyn_mr;
+  const float* dyn_alpha;
+  const float* dyn_sums;
+  int dyn_g_ld, dyn_y_ld;
 };
 
-template <int CT>
+constexpr int S_DYN_MAXN = 8;       // samples whose norm-backward constants fit the LDS table of the DYN variant
+
+// DYN: columns [8 CT, 16 CT) of dY (the unit0 half of the fused [residual | unit0] first layer) are not read but formed from the
+// gradient g behind that half's InstanceNorm + PReLU and the forward conv output y: the apply pass of the LAST norm of the backward,
+// its 201 MB write and this kernel's read of it disappear from the tail of the step, and the lower half is read from the residual
+// gradient where it lies (no copy into a fused operand).  Chunk c of staging slot j is c_thread ^ (CT (j & 1)): every thread then
+// owns as many lower-half chunks (plain loads) as upper-half ones (two loads + the arithmetic), whatever its lane.
+template <int CT, bool DYN = false>
 __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArgs P, int total_tiles) {
   // dy tile: planes of 16 channels, 32 B per voxel.  The plane pitch is 8 KiB + 32 B: the 8 lanes that store one voxel's 8 chunks
   // (4 planes x 32 B) then cover 128 distinct bytes of the bank period; with a pitch of exactly 8 KiB the four planes fell on the
@@ -297,23 +311,42 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArg
   constexpr int BUF = S_INB + DBYTES;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   typedef s16x4 __attribute__((address_space(3)))* lds_s16x4;
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF + 32];
+  static_assert(!DYN || ((CT == 2 || CT == 4) && JD % 2 == 0), "DYN: a power-of-two chunk count that divides the thread count");
+  constexpr int DYNC = 8 * CT;                         // channels of the norm (the upper half of the columns)
+  constexpr int TABB = DYN ? S_DYN_MAXN * DYNC * 16 : 0;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF + 32 + TABB];
+  float* const sDyn = reinterpret_cast<float*>(smem + 2 * BUF + 32);     // [n][channel][mean, rstd, s1, s2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q4 = lane >> 4, tq = r16 >> 2, tp = r16 & 3;
 
   StemStage stg;
   stg.init(tid, P.Yi, P.Zi);
   const int YZ = P.Yr * P.Zr;
-  int gd_byte[JD], gd_xyz[JD], gd_lds[JD];
+  const int c_thr = tid % (2 * CT);
+  const bool flip = DYN && c_thr >= CT;                // this thread's EVEN slots are upper-half chunks (else its odd ones)
+  int gd_byte[JD], gd_xyz[JD], gd_lds[JD], gy_byte[DYN ? JD / 2 : 1];
 #pragma unroll
   for (int j = 0; j < JD; ++j) {
     const int idx = tid + j * 256;
-    const int c = idx % (2 * CT), tv = idx / (2 * CT);
+    const int c0 = idx % (2 * CT), tv = idx / (2 * CT);
+    const int c = DYN ? (c0 ^ (CT * (j & 1))) : c0;
     const int tx = tv >> 6, ty = (tv >> 3) & 7, tz = tv & 7;
-    gd_byte[j] = ((tx * YZ + ty * P.Zr + tz) * P.d_ld + c * 8) * 2;
+    const int vox = tx * YZ + ty * P.Zr + tz;
+    if (DYN && c >= CT) {
+      gd_byte[j] = (vox * P.dyn_g_ld + (c - CT) * 8) * 2;
+      gy_byte[j >> 1] = (vox * P.dyn_y_ld + (c - CT) * 8) * 2;
+    } else {
+      gd_byte[j] = (vox * P.d_ld + c * 8) * 2;
+    }
     gd_xyz[j] = tx | (ty << 8) | (tz << 16);
     gd_lds[j] = (c >> 1) * DPL + tv * 32 + (c & 1) * 16;
   }
+  if constexpr (DYN) {
+    for (int i = tid; i < P.N * DYNC; i += 256) {
+      *reinterpret_cast<f32x4*>(sDyn + 4 * i) = f32x4{P.dyn_mr[2 * i], P.dyn_mr[2 * i + 1], P.dyn_sums[2 * i], P.dyn_sums[2 * i + 1]};
+    }
+  }
+  const float dyn_al = DYN ? P.dyn_alpha[0] : 1.f;
   auto origin = [&](int t, int& n, int& x0, int& y0, int& z0) {
     n = t / P.G.tiles;
     int r = t - n * P.G.tiles;
@@ -322,19 +355,63 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArg
     x0 = tx * 4; y0 = ty * 8; z0 = tz * 8;
   };
   uint32_t rg[S_J];
-  u32x4 rd[JD];
+  u32x4 rd[JD], ry[DYN ? JD / 2 : 1];
   auto gload = [&](int t) {
     int n, x0, y0, z0;
     origin(t, n, x0, y0, z0);
     const unsigned short* ib = reinterpret_cast<const unsigned short*>(P.in) + (((int64_t)n * P.Xi + 2 * x0) * P.Yi + 2 * y0) * P.Zi + 2 * z0;
     stg.load(ib, x0, y0, z0, P.Xi, P.Yi, P.Zi, rg);
-    const char* db = P.dy + ((((int64_t)n * P.Xr + x0) * P.Yr + y0) * P.Zr + z0) * P.d_ld * 2;
+    const int64_t tv0 = (((int64_t)n * P.Xr + x0) * P.Yr + y0) * P.Zr + z0;
+    const char* db = P.dy + tv0 * P.d_ld * 2;
+    const char* bE = db;                                // source of the even / odd slots of this thread
+    const char* bO = db;
+    if constexpr (DYN) {
+      const char* gb = P.dyn_g + tv0 * P.dyn_g_ld * 2;
+      bE = flip ? gb : db;
+      bO = flip ? db : gb;
+    }
 #pragma unroll
     for (int j = 0; j < JD; ++j) {
       const int xi = x0 + (gd_xyz[j] & 0xff), yi = y0 + ((gd_xyz[j] >> 8) & 0xff), zi = z0 + (gd_xyz[j] >> 16);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (xi < P.Xr && yi < P.Yr && zi < P.Zr) v = *reinterpret_cast<const u32x4*>(db + gd_byte[j]);
+      if (xi < P.Xr && yi < P.Yr && zi < P.Zr) v = *reinterpret_cast<const u32x4*>(((j & 1) ? bO : bE) + gd_byte[j]);
       rd[j] = v;
+    }
+    if constexpr (DYN) {                                // y of the thread's upper-half slots (slot 2k or 2k + 1)
+      const char* yb = P.dyn_y + tv0 * P.dyn_y_ld * 2;
+#pragma unroll
+      for (int k = 0; k < JD / 2; ++k) {
+        const int xyz = flip ? gd_xyz[2 * k] : gd_xyz[2 * k + 1];
+        const int xi = x0 + (xyz & 0xff), yi = y0 + ((xyz >> 8) & 0xff), zi = z0 + (xyz >> 16);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (xi < P.Xr && yi < P.Yr && zi < P.Zr) v = *reinterpret_cast<const u32x4*>(yb + gy_byte[k]);
+        ry[k] = v;
+      }
+    }
+  };
+  // DYN: the staged (g, y) chunks of tile t -> the dY chunks the apply pass would have stored (bf16 rounding included)
+  auto convert = [&](int t) {
+    int n, x0, y0, z0;
+    origin(t, n, x0, y0, z0);
+    const float* tab = sDyn + (n * DYNC + (c_thr & (CT - 1)) * 8) * 4;
+    f32x4 k4[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) k4[e] = *reinterpret_cast<const f32x4*>(tab + 4 * e);
+#pragma unroll
+    for (int k = 0; k < JD / 2; ++k) {
+      const u32x4 gq = flip ? rd[2 * k] : rd[2 * k + 1];
+      const int xyz = flip ? gd_xyz[2 * k] : gd_xyz[2 * k + 1];
+      const int xi = x0 + (xyz & 0xff), yi = y0 + ((xyz >> 8) & 0xff), zi = z0 + (xyz >> 16);
+      const bool ok = xi < P.Xr && yi < P.Yr && zi < P.Zr;
+      u32x4 o;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const float r0 = inorm_prelu_bwd_value(bf2f(gq[h] & 0xffffu), bf2f(ry[k][h] & 0xffffu), k4[2 * h][0], k4[2 * h][1], k4[2 * h][2], k4[2 * h][3], dyn_al);
+        const float r1 = inorm_prelu_bwd_value(bf2f(gq[h] >> 16), bf2f(ry[k][h] >> 16), k4[2 * h + 1][0], k4[2 * h + 1][1], k4[2 * h + 1][2], k4[2 * h + 1][3], dyn_al);
+        o[h] = ok ? pack2bf(r0, r1) : 0u;
+      }
+      rd[2 * k] = flip ? o : rd[2 * k];
+      rd[2 * k + 1] = flip ? rd[2 * k + 1] : o;
     }
   };
   auto sstore = [&](int buf) {
@@ -358,8 +435,10 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArg
     for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int t = blockIdx.x, cur = 0;
+  if constexpr (DYN) __syncthreads();       // constant table
   if (t < total_tiles) {
     gload(t);
+    if constexpr (DYN) convert(t);
     sstore(0);
   }
   __syncthreads();
@@ -398,6 +477,7 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArg
         for (int b = 0; b < CT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, df[b], acc[a][b], 0, 0, 0);
       }
     }
+    if constexpr (DYN) { if (tn < total_tiles) convert(tn); }      // (registers only: ahead of the barrier)
     __syncthreads();
     if (tn < total_tiles) sstore(cur ^ 1);
     __syncthreads();
@@ -413,9 +493,18 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradArg
       for (int e = 0; e < 4; ++e) slab[(int64_t)(a * 16 + 4 * q4 + e) * P.cn_pad + b * 16 + r16] = acc[a][b][e];
 }
 
+// ctseg_wgrad_desc::dyn_*: the upper half of the columns formed on load (DYN variant): 32 or 64 columns, <= S_DYN_MAXN samples
+bool wgrad_stem_dyn_ok(const ctseg_wgrad_desc* d) {
+  if (d->dyn_col0 * 2 != d->Cn || (d->Cn != 32 && d->Cn != 64) || d->N > S_DYN_MAXN) return false;
+  if (d->dyn_g_ld % 8 != 0 || d->dyn_y_ld % 8 != 0 || d->dyn_g_ld < d->dyn_col0 || d->dyn_y_ld < d->dyn_col0) return false;
+  if ((int64_t)d->Xr * d->Yr * d->Zr * d->dyn_g_ld * 2 >= (1ll << 31) || (int64_t)d->Xr * d->Yr * d->Zr * d->dyn_y_ld * 2 >= (1ll << 31)) return false;
+  return true;
+}
+
 bool wgrad_stem_eligible(const ctseg_wgrad_desc* d) {
   if (d->dtype != CTSEG_BF16 || d->ntaps != 27 || d->sin != 2 || d->Cg != 1 || d->g_ld != 1) return false;
-  if (d->Cn > 64 || d->Cn % 16 != 0 || d->d_ld % 8 != 0 || d->d_ld < d->Cn || ((uintptr_t)d->dy % 16) != 0) return false;
+  const int dcols = d->dyn_col0 > 0 ? d->dyn_col0 : d->Cn;       // columns `dy` itself holds
+  if (d->Cn > 64 || d->Cn % 16 != 0 || d->d_ld % 8 != 0 || d->d_ld < dcols || ((uintptr_t)d->dy % 16) != 0) return false;
   if (((uintptr_t)d->in % 4) != 0) return false;      // the patch is staged in aligned 4-byte pairs
   if (d->Xi != 2 * d->Xr || d->Yi != 2 * d->Yr || d->Zi != 2 * d->Zr || d->Zr < 4) return false;
   if (d->kpad_w < 32 || d->cn_pad < d->Cn) return false;
@@ -442,6 +531,13 @@ void launch_wgrad_stem(const ctseg_wgrad_desc* d, hipStream_t st) {
   a.G.tiles = stem_tiles(d->Xr, d->Yr, d->Zr); a.G.tyn = (d->Yr + 7) / 8; a.G.tzn = (d->Zr + 7) / 8;
   const int total = a.G.tiles * d->N, grid = wgrad_stem_grid(d);
   const int ct = d->Cn / 16;
+  a.dyn_g = (const char*)d->dyn_g; a.dyn_y = (const char*)d->dyn_y; a.dyn_mr = d->dyn_mean_rstd; a.dyn_alpha = d->dyn_alpha;
+  a.dyn_sums = d->dyn_sums; a.dyn_g_ld = d->dyn_g_ld; a.dyn_y_ld = d->dyn_y_ld;
+  if (d->dyn_g != nullptr) {      // (wgrad_stem_dyn_ok checked by the entry point)
+    if (ct == 2) hipLaunchKernelGGL((conv_stem_wgrad_kernel<2, true>), dim3(grid), dim3(256), 0, st, a, total);
+    else hipLaunchKernelGGL((conv_stem_wgrad_kernel<4, true>), dim3(grid), dim3(256), 0, st, a, total);
+    return;
+  }
   if (ct == 1) hipLaunchKernelGGL((conv_stem_wgrad_kernel<1>), dim3(grid), dim3(256), 0, st, a, total);
   else if (ct == 2) hipLaunchKernelGGL((conv_stem_wgrad_kernel<2>), dim3(grid), dim3(256), 0, st, a, total);
   else if (ct == 3) hipLaunchKernelGGL((conv_stem_wgrad_kernel<3>), dim3(grid), dim3(256), 0, st, a, total);

@@ -459,6 +459,7 @@ bool wgrad_up_eligible(const ctseg_wgrad_desc* d);
 int wgrad_up_slabs(const ctseg_wgrad_desc* d);
 void launch_wgrad_up(const ctseg_wgrad_desc* d, hipStream_t st);
 bool wgrad_stem_eligible(const ctseg_wgrad_desc* d);
+bool wgrad_stem_dyn_ok(const ctseg_wgrad_desc* d);
 int wgrad_stem_slabs(const ctseg_wgrad_desc* d);
 void launch_wgrad_stem(const ctseg_wgrad_desc* d, hipStream_t st);
 bool wgrad_halo_eligible(const ctseg_wgrad_desc* d);
@@ -500,6 +501,12 @@ extern "C" int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d) {
 
 extern "C" int ctseg_wgrad_in_norm_ok(const ctseg_wgrad_desc* d) { return (desc_ok(d) && d->dtype == CTSEG_BF16 && wgrad_halo_in_norm_ok(d)) ? 1 : 0; }
 
+extern "C" int ctseg_wgrad_dy_norm_ok(const ctseg_wgrad_desc* d) {
+  if (!desc_ok(d) || d->dyn_col0 <= 0 || d->in_mean_rstd != nullptr) return 0;
+  if (wgrad_halo_eligible(d) || wgrad_up_eligible(d)) return 0;
+  return (wgrad_stem_eligible(d) && wgrad_stem_dyn_ok(d)) ? 1 : 0;
+}
+
 extern "C" int ctseg_wgrad_narrow_ok(const ctseg_wgrad_desc* d) {
   if (!desc_ok(d)) return 0;
   if (wgrad_halo_eligible(d)) return 1;
@@ -512,6 +519,12 @@ extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
   CTSEG_REQUIRE(d->dtype == CTSEG_F32 || d->dtype == CTSEG_BF16, "conv_wgrad: bad dtype");
   const int SZ = d->dtype == CTSEG_F32 ? 4 : 2, EPC = 16 / SZ;
   const bool halo = wgrad_halo_eligible(d);     // also moves 12-wide bf16 rows (ctseg_wgrad_narrow_ok)
+  if (d->dyn_g != nullptr)
+    CTSEG_REQUIRE(ctseg_wgrad_dy_norm_ok(d) == 1 && d->dyn_y && d->dyn_mean_rstd && d->dyn_alpha && d->dyn_sums &&
+                      ((uintptr_t)d->dyn_g % 16) == 0 && ((uintptr_t)d->dyn_y % 16) == 0,
+                  "conv_wgrad: dyn_* (dY formed on load) is not implemented for this pass (ask ctseg_wgrad_dy_norm_ok)");
+  else
+    CTSEG_REQUIRE(d->dyn_col0 == 0, "conv_wgrad: dyn_col0 without dyn_g");
   if (d->in_mean_rstd != nullptr)
     CTSEG_REQUIRE(halo && wgrad_halo_in_norm_ok(d) && d->in_alpha != nullptr,
                   "conv_wgrad: in_mean_rstd (normalise the operand on load) is not implemented for this pass (ask ctseg_wgrad_in_norm_ok)");

@@ -127,6 +127,14 @@ template <typename H = BF16> __device__ __forceinline__ void load_n_as_float(con
   }
 }
 
+// One element of the InstanceNorm + PReLU backward (what instnorm_prelu_bwd_apply_kernel stores): shared by the apply pass and by
+// the passes that form it on load, so that both round the same way
+__device__ __forceinline__ float inorm_prelu_bwd_value(float g, float y, float mean, float rstd, float s1, float s2, float al) {
+  const float xh = (y - mean) * rstd;
+  const float dxh = g * (xh > 0.f ? 1.f : al);
+  return rstd * (dxh - s1 - xh * s2);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -366,12 +366,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_bwd_apply_kernel(const cha
     for (int e = 0; e < EPC; ++e) {
       const int c = cv * EPC + e;
       float r = 0.f;
-      if (c < C) {
-        const float rstd = tab[4 * e + 1];
-        const float xh = (yv[e] - tab[4 * e]) * rstd;
-        const float dxh = gv[e] * (xh > 0.f ? 1.f : al);
-        r = rstd * (dxh - tab[4 * e + 2] - xh * tab[4 * e + 3]);
-      }
+      if (c < C) r = inorm_prelu_bwd_value(gv[e], yv[e], tab[4 * e], tab[4 * e + 1], tab[4 * e + 2], tab[4 * e + 3], al);
       o[e] = r;
       if (COLSUM) cs[e] += r;
     }

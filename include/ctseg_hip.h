@@ -155,6 +155,20 @@ typedef struct ctseg_wgrad_desc {
   const float* in_mean_rstd;
   const float* in_alpha;
   int32_t in_norm_C;
+  /* dY formed on load (ABI 3, where ctseg_wgrad_dy_norm_ok() == 1; dyn_g == NULL: off).  Columns [dyn_col0, Cn) of dY are not read
+   * from `dy` (which then holds columns [0, dyn_col0) only, d_ld >= dyn_col0) but computed from the gradient dyn_g behind the
+   * InstanceNorm + PReLU of those columns and its forward input dyn_y — element for element what
+   * ctseg_instnorm_prelu_bwd_apply(dyn_g, dyn_y, dyn_mean_rstd, dyn_alpha, dyn_sums) would have stored, bf16 rounding included.
+   * For the FIRST layer of a network (no input gradient wanted) this removes the last norm-backward pass of the step and the copy
+   * of the residual gradient into a fused [d_res | d_y0] operand
+   * (reference: the first ResidualUnit of the MONAI UNet built at capstone/volumetric/base_trainer.py:65-72). */
+  int32_t dyn_col0;
+  const void* dyn_g;           /* [N][rows][dyn_g_ld], channel c <-> column dyn_col0 + c */
+  const void* dyn_y;           /* [N][rows][dyn_y_ld] */
+  int32_t dyn_g_ld, dyn_y_ld;
+  const float* dyn_mean_rstd;  /* [N][Cn - dyn_col0][2] */
+  const float* dyn_alpha;
+  const float* dyn_sums;       /* [N][Cn - dyn_col0][2]: ctseg_instnorm_prelu_bwd_finalize's output */
 } ctseg_wgrad_desc;
 
 int ctseg_wgrad_tile_cols(int32_t Cn);
@@ -165,6 +179,8 @@ int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d);
 int ctseg_wgrad_narrow_ok(const ctseg_wgrad_desc* d);
 /* 1 when this weight-gradient pass can normalise its gathered operand on the fly (the 16 -> <= 16 channel LDS-halo kernel) */
 int ctseg_wgrad_in_norm_ok(const ctseg_wgrad_desc* d);
+/* 1 when this weight-gradient pass can form the upper columns of dY on load (dyn_*): the single-channel stride-2 first layer */
+int ctseg_wgrad_dy_norm_ok(const ctseg_wgrad_desc* d);
 int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream);
 /* dw[(b*A + a)*T + t] = sum_s ws[s][t*Astride + a][col0 + b]  for a < A, b < nb;
  * db[b] = sum_s ws[s][T*Astride][col0+b] (db may be NULL).  Astride = the pass's (padded) Cg. */

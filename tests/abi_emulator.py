@@ -7,6 +7,7 @@ oracle WITHOUT a GPU.  fp32 storage only.  It is also the per-kernel specificati
 compare the HIP kernels with.  Never imported by the product.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -123,7 +124,16 @@ class Emulator:
         assert d.dtype == F32
         N, Cg, Cn = d.N, d.Cg, d.Cn
         inp = cl_view(d.in_, N, d.Xi, d.Yi, d.Zi, Cg, d.g_ld)
-        dy = cl_view(d.dy, N, d.Xr, d.Yr, d.Zr, Cn, d.d_ld)
+        if d.dyn_g:      # ctseg_wgrad_desc::dyn_*: the upper columns of dY formed from (g, y) of the norm behind them
+            c0, C2, S = d.dyn_col0, Cn - d.dyn_col0, d.Xr * d.Yr * d.Zr
+            xh, rstd = self._xhat(d.dyn_y, d.dyn_y_ld, d.dyn_mean_rstd, N, S, C2)
+            gv = self._rows(d.dyn_g, N, S, C2, d.dyn_g_ld)
+            sm = mem(d.dyn_sums, N * C2 * 2).reshape(N, 1, C2, 2)
+            dxh = gv * np.where(xh > 0, 1.0, mem(d.dyn_alpha, 1)[0]).astype(np.float32)
+            up = (rstd * (dxh - sm[..., 0] - xh * sm[..., 1])).astype(np.float32)
+            dy = np.concatenate([self._rows(d.dy, N, S, c0, d.d_ld), up], axis=2).reshape(N, d.Xr, d.Yr, d.Zr, Cn)
+        else:
+            dy = cl_view(d.dy, N, d.Xr, d.Yr, d.Zr, Cn, d.d_ld)
         ws = mem(d.ws, N * d.splits * d.kpad_w * d.cn_pad).reshape(N * d.splits, d.kpad_w, d.cn_pad)
         ws[:] = 0
         dyf = dy.reshape(-1, Cn)
@@ -442,7 +452,9 @@ def patch_native(nat, emu):
     nat.require_gpu = lambda t, what: None
     orig_query = nat.query
     own = {"ctseg_conv_split_ok": emu.conv_split_ok, "ctseg_conv_narrow_ok": lambda d: 0, "ctseg_wgrad_narrow_ok": lambda d: 0,
-           "ctseg_conv_bwd_stats_slots": lambda d: 1}
+           "ctseg_conv_bwd_stats_slots": lambda d: 1,
+           # (the library offers dY-on-load for bf16 storage only; the emulated fp32 plans take the branch so that its host logic runs)
+           "ctseg_wgrad_dy_norm_ok": lambda d: 1 if os.environ.get("CTSEG_EMU_WGRAD_DYN", "1") == "1" else 0}
     nat.query = lambda name, d: own[name](d) if name in own else orig_query(name, d)
 
     def undo():

@@ -282,3 +282,38 @@ def test_backward_norm_statistics_from_the_conv_epilogue_equal_the_reduce_pass(m
     assert diffs[first][0] < 1e-5, diffs
     assert max(d for d, _ in diffs) < 2e-2, diffs
     assert cos > 0.99999, cos
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# dY formed on load by the first layer's weight-gradient pass (ctseg_wgrad_desc::dyn_*)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,filters", [((2, 64, 64, 32), [32, 64, 128, 256]), ((1, 36, 44, 20), [32, 64]), ((3, 20, 24, 12), [16, 32]),
+                                           ((2, 40, 72, 48), [32, 64, 128])])
+def test_first_layer_weight_gradient_with_dy_formed_on_load_equals_the_apply_pass(monkeypatch, shape, filters):
+    """The first layer wants no input gradient: conv_stem_wgrad reads d_res where it lies and forms d_y0 from (g, y) of unit0's norm
+    with the apply pass's own arithmetic (inorm_prelu_bwd_value, rounded to bf16 as the store would have) — one norm-backward pass
+    and one copy of g fewer, the SAME flat gradient bit for bit (same values into the same summation order).  Ragged tiles, 1-3
+    samples, 32- and 64-column first layers."""
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    B, H, W, D = shape
+    g = torch.Generator().manual_seed(17)
+    images = torch.randn(B, 1, H, W, D, generator=g).to(DEV)
+    masks = (torch.rand(B, 9, H, W, D, generator=g) < 0.08).to(torch.uint8).to(DEV)
+    ind = torch.ones(B, 9, dtype=torch.float64).to(DEV)
+    out = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("CTSEG_WGRAD_DYN", on)
+        torch.manual_seed(23)
+        m = BaseUNet3D(filters=list(filters), loss_fx=["CrossEntropy"], precision="bf16").to(DEV)
+        loss = float(m.fit_step((images, masks, ind), keep_logits=False))
+        eng = m.unet.engine()
+        plan = eng.last_plan
+        names = [nm for nm, *_ in plan.bwd]
+        n_dyn = sum(1 for nm, _, a in plan.bwd if nm == "ctseg_conv_wgrad" and a[0].dyn_g)
+        torch.cuda.synchronize()
+        out[on] = (loss, eng.store.flat_g.clone(), sum(1 for nm in names if nm.startswith("ctseg_instnorm_prelu_bwd_apply")), n_dyn)
+    a, b = out["0"], out["1"]
+    assert a[3] == 0 and b[3] == 1 and b[2] == a[2] - 1, (a[2:], b[2:])
+    assert a[0] == b[0]
+    assert torch.isfinite(b[1]).all()
+    assert torch.equal(a[1], b[1]), float((a[1] - b[1]).abs().max())

@@ -446,3 +446,38 @@ def test_backward_statistics_come_from_the_producing_pass_where_it_offers_them(e
     assert n_norms >= 8 and counts["0"][0] == n_norms and not any(counts["0"][1])
     fused = sum(counts["1"][1])
     assert fused == n_norms and counts["1"][0] == 0, counts      # every norm's gradient is written by a convolution pass here
+
+
+def test_first_layer_weight_gradient_forms_its_upper_columns_on_load(emu):
+    """ctseg_wgrad_desc::dyn_* (round 3): the first layer of the network wants no input gradient, so the weight-gradient pass of its
+    fused [residual | unit0] convolution reads d_res where it lies and forms d_y0 from (g, y) of unit0's norm on load — that norm has
+    no apply pass, nobody copies g into a fused operand, and its slope gradient comes from ctseg_instnorm_prelu_dalpha.  The
+    gradients are torch's either way (the emulator offers the feature for fp32 plans; the library for the bf16 first layer)."""
+    import os
+    seen = {}
+    for on in ("1", "0"):
+        os.environ["CTSEG_EMU_WGRAD_DYN"] = on
+        try:
+            ref, net = _pair(3, 1, 10, (4, 8, 16), (2, 2), 2, seed=5)
+            g = torch.Generator().manual_seed(4)
+            x = torch.randn(2, 1, 8, 8, 4, generator=g)
+            gy = torch.randn(2, 10, 8, 8, 4, generator=g)
+            ref(x).backward(gy)
+            eng = net.engine()
+            eng.forward(x)
+            pl = eng.last_plan
+            pl.dlogits.t[..., :10].copy_(gy.permute(0, 2, 3, 4, 1))
+            eng.backward(pl)
+            for (k, p), q in zip(ref.named_parameters(), net.parameters()):
+                np.testing.assert_allclose(eng.store.grad_view(q).numpy(), p.grad.numpy(), err_msg=k, **_tol(k, p.grad.numpy()))
+            names = [nm for nm, *_ in pl.bwd]
+            dyn = [a[0] for nm, _, a in pl.bwd if nm == "ctseg_conv_wgrad" and a[0].dyn_g]
+            seen[on] = (sum(1 for nm in names if nm.startswith("ctseg_instnorm_prelu_bwd_apply")), names.count("ctseg_instnorm_prelu_dalpha"),
+                        len(dyn), eng.store.flat_g.clone())
+            if on == "1":
+                assert len(dyn) == 1 and dyn[0].dyn_col0 * 2 == dyn[0].Cn and dyn[0].d_ld >= dyn[0].dyn_col0
+        finally:
+            os.environ.pop("CTSEG_EMU_WGRAD_DYN", None)
+    assert seen["0"][2] == 0 and seen["0"][1] == 0
+    assert seen["1"][0] == seen["0"][0] - 1 and seen["1"][1] == 1, seen        # one apply pass fewer, one slope-gradient launch instead
+    np.testing.assert_allclose(seen["1"][3].numpy(), seen["0"][3].numpy(), rtol=1e-5, atol=1e-7)
