@@ -326,6 +326,10 @@ bool conv_halo_sw_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_halo_sw_slots(const ConvKArgs& a);
 int conv_halo_sw_bst_slots(const ConvKArgs& a, int nclass);   // 0: this pass cannot take ConvKArgs::bst
 void launch_conv_halo_sw(ConvKArgs& a, int nclass, hipStream_t st);
+// conv_up8.hip: 8-class stride-2 passes with >= 128 gathered channels and 64 columns: all classes' accumulators live, K chunked
+bool conv_up8_eligible(const ConvKArgs& a, int dtype, int nclass);
+int conv_up8_slots(const ConvKArgs& a);
+void launch_conv_up8(ConvKArgs& a, hipStream_t st);
 // conv_down_halo.hip: stride-2 3x3x3 conv with 16 / 32 gathered channels, 64 columns per workgroup, bf16
 bool conv_down_halo_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_down_halo_slots(const ConvKArgs& a);

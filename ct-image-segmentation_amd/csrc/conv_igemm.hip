@@ -309,6 +309,7 @@ static int bst_slots_for(const ConvKArgs& a, int dtype, int nclass, bool smallc)
   if (conv_halo_sw_eligible(a, dtype, nclass)) return conv_halo_sw_bst_slots(a, nclass);
   if (conv_down_halo_eligible(a, dtype, nclass)) return conv_down_halo_bst_slots(a);
   if (conv_down_r_eligible(a, dtype, nclass)) return 0;
+  if (conv_up8_eligible(a, dtype, nclass)) return 0;
   { const char* e = getenv("CTSEG_BST_GENERIC"); if (e != nullptr && e[0] == '0') return 0; }   // (A/B switch)
   // generic / ring kernels (conv_epilogue): one partial row per (class, tile); whole 16-byte chunks of y beside those of the output
   if (smallc || a.out2 != nullptr || a.o_ld % 8 != 0 || a.Cn_store % 8 != 0 || a.bst.col0 % 8 != 0 || a.bst.y_ld % 8 != 0 ||
@@ -431,7 +432,11 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   const bool sw = !halo && !up && !stem && conv_halo_sw_eligible(a, d->dtype, d->nclass);
   const bool down = !halo && !up && !stem && !sw && conv_down_halo_eligible(a, d->dtype, d->nclass);
   const bool downr = !halo && !up && !stem && !sw && !down && conv_down_r_eligible(a, d->dtype, d->nclass);
-  if (d->stats && downr) {
+  const bool up8 = !halo && !up && !stem && !sw && !down && !downr && conv_up8_eligible(a, d->dtype, d->nclass);
+  if (d->stats && up8) {
+    CTSEG_REQUIRE(d->stats_tile0 + conv_up8_slots(a) <= d->stats_tiles && d->stats_ld >= d->Cn,
+                  "conv_igemm: stats partial layout (many-channel 8-class pass)");
+  } else if (d->stats && downr) {
     CTSEG_REQUIRE(d->stats_tile0 + conv_down_r_slots(a) <= d->stats_tiles && d->stats_ld >= d->Cn,
                   "conv_igemm: stats partial layout (stride-2 register-weight pass)");
   } else if (d->stats && down) {
@@ -466,6 +471,7 @@ extern "C" int ctseg_conv_igemm(const ctseg_conv_desc* d, void* stream) {
   else if (sw) launch_conv_halo_sw(a, d->nclass, st);
   else if (down) launch_conv_down_halo(a, st);
   else if (downr) launch_conv_down_r(a, st);
+  else if (up8) launch_conv_up8(a, st);
   else if (d->dtype == CTSEG_F32) launch_dtype<float>(a, smallc, d->nclass, st);
   else if (d->dtype == CTSEG_F16) launch_dtype<F16>(a, smallc, d->nclass, st);
   else launch_dtype<BF16>(a, smallc, d->nclass, st);
@@ -545,6 +551,7 @@ extern "C" int ctseg_conv_num_tiles(const ctseg_conv_desc* d) {
   if (conv_halo_sw_eligible(a, d->dtype, d->nclass)) return conv_halo_sw_slots(a);
   if (conv_down_halo_eligible(a, d->dtype, d->nclass)) return conv_down_halo_slots(a);
   if (conv_down_r_eligible(a, d->dtype, d->nclass)) return conv_down_r_slots(a);
+  if (conv_up8_eligible(a, d->dtype, d->nclass)) return conv_up8_slots(a);
   const int SZq = d->dtype == CTSEG_F32 ? 4 : 2, EPCq = 16 / SZq;
   const bool smallq = (d->Cg % EPCq) != 0 || (d->g_ld % EPCq) != 0 || ((uintptr_t)d->in % 16) != 0;
   const int bm = tile_rows_for(a, d->dtype, smallq, d->nclass);

@@ -130,6 +130,17 @@ def test_ring_pipelined_tile_vs_torch_cpu(kind, cin, cout, shape):
     _check_conv_module(kind, cin, cout, shape)
 
 
+@pytest.mark.parametrize("kind,cin,cout,shape", [("convT", 384, 64, (1, 16, 16, 8)), ("convT", 384, 64, (2, 10, 18, 12)),
+                                                 ("convT", 256, 64, (1, 6, 20, 18)), ("conv_s2", 64, 256, (1, 36, 40, 12)),
+                                                 ("conv_s2", 64, 384, (2, 32, 32, 8)), ("convT", 128, 64, (1, 3, 30, 26))])
+def test_many_channel_8_class_kernel_vs_torch_cpu(kind, cin, cout, shape):
+    """8-class stride-2 passes with >= 128 gathered channels and 64 columns take conv_up8_kernel (all classes' accumulators live, K
+    walked in 32-channel chunks, delta-major taps): ConvTranspose3d 384 / 256 / 128 -> 64 forward and the input gradient of a stride-2
+    Conv3d 64 -> 256 / 384 (Cg = 256 / 384).  >= 2048 coarse voxels, ragged 2 x 8 x 8 tiles on every axis, both tile-axis mappings,
+    1-2 samples."""
+    _check_conv_module(kind, cin, cout, shape)
+
+
 @pytest.mark.parametrize("kind,cin,cout,shape", [("conv", 64, 64, (1, 16, 16, 16)), ("conv_s2", 32, 128, (2, 32, 32, 16)),
                                                  ("convT", 64, 16, (2, 16, 16, 16)), ("conv", 128, 256, (1, 16, 16, 16))])
 def test_weight_gradient_with_xcd_grouped_slabs_vs_torch_cpu(kind, cin, cout, shape):
