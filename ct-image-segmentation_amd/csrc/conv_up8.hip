@@ -9,14 +9,18 @@
 // 98 KB plus 1.33 MB of class weights from L2 to LDS (4 MB; 13 TB/s over the launch: L2-bandwidth bound at 22 % MFMA), and the 1- and
 // 2-tap classes are K loops of 6-12 stages whose prologue is exposed.  Here:
 //
-//  * a workgroup owns a 2 x 8 x 8 coarse tile and keeps the accumulators of ALL 8 classes in registers (a wave: 2 row tiles x 2 column
-//    tiles x 8 classes = 128 registers), walking K in chunks of 32 channels; nothing is stored until the last chunk, so the input halo
-//    (3 x 9 x 9 voxels: the taps only reach offsets 0 / +1) is read ONCE per tile and chunk instead of once per tap: 1.33 MB of weights
-//    + 0.19 MB of halo per 128 coarse voxels;
-//  * per chunk the 27 (class, tap) weight blocks [64 columns][32 k] stream through a three-slot LDS ring, nine blocks per stage, with
-//    direct-to-LDS loads two stages ahead (counted vmcnt waits; every wave issues the same number of loads per stage);
-//  * the (class, tap) pairs are walked DELTA-major: the 8 shifted operand fragments x[r + delta] are read once per chunk and feed
-//    every class that has the tap (16 operand reads + 54 weight reads per 108 MFMAs and wave);
+//  * a workgroup owns a 3 x 8 x 8 coarse tile (192 voxels: the 6-deep level is two tiles deep, 256 tiles at the reference's size)
+//    and ONE of two class groups — {0, 3, 7} (1 + 4 + 8 = 13 taps) or {1, 2, 4, 5, 6} (2 + 2 + 2 + 4 + 4 = 14 taps) — and keeps the
+//    accumulators of all its classes in registers (a wave: 3 row tiles x 2 column tiles x <= 5 classes = 120 registers), walking K in
+//    chunks of 32 channels; nothing is stored until the last chunk, so the input halo (4 x 9 x 9 voxels: the taps only reach offsets
+//    0 / +1) is read once per tile, chunk and group instead of once per tap.  Per 192 coarse voxels and chunk a workgroup streams
+//    <= 56 KB of weights + 23 KB of halo.  (A first version with all 8 classes in one workgroup of 128 voxels streamed 110 + 18 KB
+//    per chunk, was bound by exactly that stream — 0.108 ms with or without its MFMAs — and left a quarter of the chip idle in its
+//    second round of tiles.)
+//  * per chunk the group's (class, tap) weight blocks [64 columns][32 k] stream through a five-slot LDS ring, five blocks per stage,
+//    with direct-to-LDS loads FOUR stages ahead (counted vmcnt waits; every wave issues the same number of loads per stage);
+//  * the (class, tap) pairs are walked DELTA-major: the shifted operand fragments x[r + delta] are read once per chunk and feed every
+//    class of the group that has the tap;
 //  * the halo chunk of the next K chunk is staged by LDS-DMA (raw buffer loads ... lds, out-of-range offsets deliver zeros) into the
 //    other of two buffers; conv_halo_sw.hip's plane layout and lane <-> voxel permutation keep every ds_read_b128 conflict free;
 //  * epilogue as conv_halo_sw.hip's: v_permlane16_swap -> 16-byte channels-last stores, InstanceNorm partials per workgroup.
@@ -24,17 +28,18 @@
 #include <type_traits>
 
 #ifndef U8_ABL
-#define U8_ABL 0     // timing-only ablation: 1 no MFMAs, 2 no LDS operand reads, 4 no weight stream, 8 no halo loads
+#define U8_ABL 0     // timing-only ablation: 1 no MFMAs, 2 no LDS operand reads, 4 no weight stream, 8 no halo loads, 16 no x operand reads, 32 no weight operand reads
 #endif
 
 namespace ctseg {
 
-constexpr int U8_NTHR = 512, U8_CN = 64, U8_TA = 2;
-constexpr int U8_HV = 280;                                  // (TA + 1) x 9 rows of 10 slots = 270, padded to 8 (mod 16)
+constexpr int U8_NTHR = 512, U8_CN = 64, U8_TA = 3;
+constexpr int U8_HV = 360;                                  // (TA + 1) x 9 rows of 10 slots (= 8 mod 16: conv_halo_sw.hip)
 constexpr int U8_PLANE = U8_HV * 16;
-constexpr int U8_HBUF = 1152 * 16;                          // 4 planes (1120 slots) + the overhang of the last DMA piece's wave
+constexpr int U8_HBUF = 1472 * 16;                          // 4 planes (1440 slots) + the overhang of the last DMA piece's wave
 constexpr int U8_TAPB = U8_CN * 64;                         // one (class, tap) block of a 32-channel chunk: 64 rows x 64 B
-constexpr int U8_STAGE = 9 * U8_TAPB, U8_RING = 3 * U8_STAGE;
+constexpr int U8_ST = 5, U8_NS = 3;                         // blocks per ring stage, stages per chunk (13 / 14 blocks: 5 + 5 + 3 / 4)
+constexpr int U8_STAGE = U8_ST * U8_TAPB, U8_SLOTS = 5, U8_RING = U8_SLOTS * U8_STAGE;      // look-ahead: four stages
 constexpr int U8_TOTAL = 2 * U8_HBUF + U8_RING + 8 * 2 * U8_CN * 4 + 64 * 4;
 static_assert(U8_TOTAL <= 160 * 1024, "LDS");
 
@@ -60,22 +65,19 @@ constexpr int u8_tap_index(int c, int delta) {
   const int ix = px ? 1 - dx : 0, iy = py ? 1 - dy : 0, iz = pz ? 1 - dz : 0;
   return (ix * (1 + py) + iy) * (1 + pz) + iz;
 }
-// the 27 (class, tap) pairs in delta-major order: position -> delta / class
-constexpr int u8_pos_delta(int pos) {
+// class groups and their (class, tap) pairs in delta-major order: position -> delta / class slot (index into the group)
+constexpr int u8_ncls(int grp) { return grp == 0 ? 3 : 5; }
+constexpr int u8_gclass(int grp, int i) { return grp == 0 ? (i == 0 ? 0 : i == 1 ? 3 : 7) : (i == 0 ? 1 : i == 1 ? 2 : i == 2 ? 4 : i == 3 ? 5 : 6); }
+constexpr int u8_npos(int grp) { return grp == 0 ? 13 : 14; }
+constexpr int u8_pos_find(int grp, int pos, int what) {     // what: 0 delta, 1 class slot
   int n = 0;
   for (int d = 0; d < 8; ++d)
-    for (int c = 0; c < 8; ++c)
-      if ((c & d) == d) { if (n == pos) return d; ++n; }
+    for (int i = 0; i < u8_ncls(grp); ++i)
+      if ((u8_gclass(grp, i) & d) == d) { if (n == pos) return what == 0 ? d : i; ++n; }
   return -1;
 }
-constexpr int u8_pos_class(int pos) {
-  int n = 0;
-  for (int d = 0; d < 8; ++d)
-    for (int c = 0; c < 8; ++c)
-      if ((c & d) == d) { if (n == pos) return c; ++n; }
-  return -1;
-}
-static_assert(u8_pos_delta(26) == 7 && u8_pos_class(26) == 7 && u8_pos_delta(8) == 1 && u8_pos_class(8) == 1, "delta-major list");
+static_assert(u8_pos_find(0, 12, 0) == 7 && u8_pos_find(0, 12, 1) == 2 && u8_pos_find(0, 13, 0) == -1, "group 0: 13 pairs");
+static_assert(u8_pos_find(1, 13, 0) == 6 && u8_pos_find(1, 13, 1) == 4 && u8_pos_find(1, 14, 0) == -1, "group 1: 14 pairs");
 
 struct Up8Geom {
   int da, db, dc;            // extents of the coarse (row) grid along the tile axes (a = short axis)
@@ -84,6 +86,7 @@ struct Up8Geom {
   int pa, pb, pc;            // which volume axis (0 = x, 1 = y, 2 = z) each tile axis runs along
   int tbn, tcn, tiles;       // tiles along b, c; tiles per sample
   int in_sample_bytes, out_sample_bytes, add_sample_bytes;
+  int gxs;                   // spatial workgroups: the grid is 2 * gxs, workgroup L takes class group L / gxs
 };
 
 __device__ __forceinline__ void u8_patch_voxel(int r16, int& db, int& c) {
@@ -92,41 +95,41 @@ __device__ __forceinline__ void u8_patch_voxel(int r16, int& db, int& c) {
 }
 
 // ZXY: the tile axes (a, b, c) run along the volume axes (z, x, y) instead of (x, y, z) — compile time, so that the halo offset of a
-// shift is an instruction immediate.  (The first version of this kernel spent 165 non-MFMA instructions per stage and wave around
-// 36 MFMAs — 64-bit source addresses of the DMA pieces, bounds tests per chunk, operand address adds — and was bound by their issue:
-// with MFMAs, operand reads and both DMA streams compiled out it still took 0.072 of its 0.108 ms.)
-template <typename H, bool STATS, bool ZXY>     // H = 16-bit storage kind (BF16 / F16)
-__global__ __launch_bounds__(U8_NTHR) void conv_up8_kernel(const ConvKArgs P, const Up8Geom G, int total_tiles) {
-  __shared__ __attribute__((aligned(16))) char smem[U8_TOTAL];
+// shift is an instruction immediate; GRP: the class group.  (The first version of this kernel spent 165 non-MFMA instructions per
+// stage and wave around 36 MFMAs — 64-bit source addresses of the DMA pieces, bounds tests per chunk, operand address adds.)
+template <typename H, bool STATS, bool ZXY, int GRP>     // H = 16-bit storage kind (BF16 / F16)
+__device__ __forceinline__ void conv_up8_body(const ConvKArgs& P, const Up8Geom& G, int total_tiles, char* smem) {
+  constexpr int NCLS = u8_ncls(GRP), NPOS = u8_npos(GRP);
   char* const sH = smem;
   char* const sW = smem + 2 * U8_HBUF;
   float* const sStats = reinterpret_cast<float*>(sW + U8_RING);
-  int* const sTab = reinterpret_cast<int*>(sStats + 8 * 2 * U8_CN);       // [0,32) weight element offset of position, [32,64) its kpad
+  int* const sTab = reinterpret_cast<int*>(sStats + 8 * 2 * U8_CN);       // [0,16) weight element offset of position, [16,32) its kpad
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, q4 = lane >> 4;
   const int NKC = P.Cg / 32;
+  const int sid = blockIdx.x % G.gxs;                         // spatial workgroup index inside the group
 
-  if (tid < 32) {
+  if (tid < 16) {
     int wo = 0, kp = 0;
-    if (tid < 27) {
-      const int c = u8_pos_class(tid), ti = u8_tap_index(c, u8_pos_delta(tid));
+    if (tid < NPOS) {
+      const int c = u8_gclass(GRP, u8_pos_find(GRP, tid, 1)), ti = u8_tap_index(c, u8_pos_find(GRP, tid, 0));
       wo = (int)(P.cls[c].w_off + (int64_t)ti * P.Cg);
       kp = P.cls[c].kpad;
     }
-    sTab[tid] = wo; sTab[32 + tid] = kp;
+    sTab[tid] = wo; sTab[16 + tid] = kp;
   }
 
-  // ---- halo DMA: three rounds of 512 16-byte pieces cover the 4 planes x 280 slots of a chunk (the third: waves 0-1; the others
-  // repeat their second piece so that every wave issues the same number of loads) ----------------------------------------------
+  // ---- halo DMA: three rounds of 512 16-byte pieces cover the 4 planes x 360 slots of a chunk (the third: waves 0-6; wave 7 repeats
+  // its second piece so that every wave issues the same number of loads) ----------------------------------------------------------
   int h_off[3], h_abc[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    const int idx = (r == 2 && wave >= 2) ? tid + 512 : tid + r * 512;
+    const int idx = (r == 2 && wave == 7) ? tid + 512 : tid + r * 512;
     const int pl = idx / U8_HV, s = idx - pl * U8_HV;
     const int ha = s / 90, rem = s - ha * 90, hb = rem / 10, hc = rem - hb * 10 - 1;     // halo coordinates minus one: 0 .. TA / 8 / 8
-    const bool ok = idx < 4 * U8_HV && s < 270 && hc >= 0;
+    const bool ok = idx < 4 * U8_HV && hc >= 0;
     h_off[r] = (ha * G.ia + hb * G.ib + hc * G.ic) * P.g_ld * 2 + pl * 16;
     h_abc[r] = ok ? (ha | (hb << 8) | (hc << 16)) : 0x7f7f7f;
   }
@@ -155,45 +158,49 @@ __global__ __launch_bounds__(U8_NTHR) void conv_up8_kernel(const ConvKArgs P, co
   auto issue_halo = [&](int kc, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const int base = ((r == 2 && wave >= 2) ? 512 : r * 512) + wave * 64;
+      const int base = ((r == 2 && wave == 7) ? 512 : r * 512) + wave * 64;
       u8_raw_buffer_load_lds(h_rs, (u8_lds_u32_ptr)(sH + buf * U8_HBUF + base * 16), 16, h_v[r], h_soff + kc * 64, 0, 0);
     }
   };
 
-  // ---- weight stream: stage s of chunk kc = positions 9 s .. 9 s + 8; piece = tid + 512 g (g < 5; the nonexistent tenth block of
-  // waves 4-7 repeats their g = 3 piece); LDS image lane-linear, the swizzle (16-byte slot ^ ((row >> 2) & 3)) on the source side ----
-  // The byte offset of every piece from the packed operand's base is a per-thread constant (15 registers); the chunk moves a scalar.
-  const int w_row = (tid & 255) >> 2, w_src = ((tid & 3) ^ ((w_row >> 2) & 3)) * 8;
+  // ---- weight stream: stage s of a chunk = positions 5 s .. 5 s + 4 (the last stage: 3 / 4 real ones); piece = tid + 512 g, g < 3:
+  // block (tid >> 8) + 2 g of the stage, the sixth of waves 4-7 repeats their g = 1 piece; LDS image lane-linear, the swizzle
+  // (16-byte slot ^ ((row >> 1) & 3)) on the source side.  The byte offset of every piece from the packed operand's base is a
+  // per-thread constant (out of range for the positions a group does not have); the chunk moves a scalar --------------------------
+  // swizzle: 16-byte slot ^ ((row >> 1) & 3).  (tools/probes/probe_lds_b128_patterns.hip: with the 64-byte row pitch of a 32-k block
+  // this is the conflict-free one — 116 TB/s of ds_read_b128 over the chip, as the linear pattern; ^ ((row >> 2) & 3), ^ (row & 3) or
+  // none: 75-77 TB/s.  The first layout used (row >> 2): 47 % of its LDS cycles were bank conflicts, all on the weight fragments.)
+  const int w_row = (tid & 255) >> 2, w_src = ((tid & 3) ^ ((w_row >> 1) & 3)) * 8;
   const u8i32x4 w_rs = u8_make_rsrc(P.w, 0x7fffffffu);
   __syncthreads();                                   // tables visible
-  int w_v[3][5];
+  int w_v[U8_NS][3];
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
+  for (int s = 0; s < U8_NS; ++s)
 #pragma unroll
-    for (int g = 0; g < 5; ++g) {
-      const int ge = (g == 4 && wave >= 4) ? 3 : g;
-      const int pos = 9 * s + (tid >> 8) + 2 * ge;
-      w_v[s][g] = (sTab[pos] + w_row * sTab[32 + pos] + w_src) * 2;        // < 2^31 (host-checked)
+    for (int g = 0; g < 3; ++g) {
+      const int ge = (g == 2 && wave >= 4) ? 1 : g;
+      const int pos = U8_ST * s + (tid >> 8) + 2 * ge;
+      w_v[s][g] = (pos < NPOS && !(U8_ABL & 4)) ? (sTab[pos] + w_row * sTab[16 + pos] + w_src) * 2 : (int)0x80000000;        // < 2^31 (host-checked)
     }
-  auto issue_w = [&](int kc, auto SC) __attribute__((always_inline)) {       // -> ring slot s
+  auto issue_w = [&](int kc, auto SC, int slot) __attribute__((always_inline)) {       // stage s of chunk kc -> ring slot
     constexpr int s = decltype(SC)::value;
 #pragma unroll
-    for (int g = 0; g < 5; ++g) {
-      const int ge = (g == 4 && wave >= 4) ? 3 : g;
-      if (U8_ABL & 4) continue;
-      u8_raw_buffer_load_lds(w_rs, (u8_lds_u32_ptr)(sW + s * U8_STAGE + (wave * 64 + ge * 512) * 16), 16, w_v[s][g], kc * 64, 0, 0);
+    for (int g = 0; g < 3; ++g) {
+      const int ge = (g == 2 && wave >= 4) ? 1 : g;
+      u8_raw_buffer_load_lds(w_rs, (u8_lds_u32_ptr)(sW + slot * U8_STAGE + (wave * 64 + ge * 512) * 16), 16, w_v[s][g], kc * 64, 0, 0);
     }
   };
 
   // ---- per-lane constants -----------------------------------------------------------------------------------------------------
   int pdb, pc;
   u8_patch_voxel(r16, pdb, pc);
-  const int rp = wave >> 1, ch = wave & 1;                  // row-tile pair, column half
-  int abase[2], va[2], vb[2];
+  const int trip = wave >> 1, ch = wave & 1;                // row-tile triple, column half
+  int abase[3], va[3], vb[3];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    va[rt] = rp >> 1;
-    vb[rt] = 2 * (2 * (rp & 1) + rt) + pdb;
+  for (int rt = 0; rt < 3; ++rt) {
+    const int r = 3 * trip + rt;                            // row tile 0..11 = (a plane, b pair)
+    va[rt] = r >> 2;
+    vb[rt] = 2 * (r & 3) + pdb;
     abase[rt] = ((va[rt] * 9 + vb[rt]) * 10 + pc + 1) * 16 + q4 * U8_PLANE;
   }
   // halo byte offset of shift delta = (dx,dy,dz) bits: its components along the tile axes (a, b, c) = (z, x, y) or (x, y, z)
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(U8_NTHR) void conv_up8_kernel(const ConvKArgs P, co
   };
   int wro[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) wro[j] = ((ch * 2 + j) * 16 + r16) * 64 + ((q4 ^ ((r16 >> 2) & 3)) << 4);
+  for (int j = 0; j < 2; ++j) wro[j] = ((ch * 2 + j) * 16 + r16) * 64 + ((q4 ^ ((r16 >> 1) & 3)) << 4);
   const bool af32 = P.add_f32 != 0;
   const int ASZ = af32 ? 4 : 2;
   float bias[2][4];
@@ -245,46 +252,47 @@ __global__ __launch_bounds__(U8_NTHR) void conv_up8_kernel(const ConvKArgs P, co
     __syncthreads();
   };
 
-  f32x4 acc[8][2][2];
+  f32x4 acc[NCLS][3][2];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[c][rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  // one ring stage: positions 9 S .. 9 S + 8 against the halo chunk in buffer hb
-  auto compute = [&](auto SC, int hb) __attribute__((always_inline)) {
+  // one ring stage: positions 5 S .. 5 S + 4 of the group against the halo chunk in buffer hb, weights in ring slot `slot`
+  auto compute = [&](auto SC, int hb, int slot) __attribute__((always_inline)) {
     constexpr int S = decltype(SC)::value;
     const char* hs = sH + hb * U8_HBUF;
-    const char* ws = sW + S * U8_STAGE;
-    u32x4 xf[2];
+    const char* ws = sW + slot * U8_STAGE;
+    u32x4 xf[3];
     auto tap = [&](auto TC) __attribute__((always_inline)) {        // (position, shift and class are compile-time: acc[C] is a register name)
-      constexpr int tpi = decltype(TC)::value, pos = 9 * S + tpi;
-      constexpr int D = u8_pos_delta(pos), C = u8_pos_class(pos);
-      if constexpr (tpi == 0 || D != u8_pos_delta(pos > 0 ? pos - 1 : 0)) {
+      constexpr int tpi = decltype(TC)::value, pos = U8_ST * S + tpi;
+      if constexpr (pos < NPOS) {
+        constexpr int D = u8_pos_find(GRP, pos, 0), C = u8_pos_find(GRP, pos, 1);
+        if constexpr (tpi == 0 || D != u8_pos_find(GRP, pos > 0 ? pos - 1 : 0, 0)) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-          xf[rt] = (U8_ABL & 2) ? u32x4{(uint32_t)(D + rt), 1u, 2u, 3u} : *reinterpret_cast<const u32x4*>(hs + abase[rt] + doff(D));
-      }
-      u32x4 wf[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        wf[j] = (U8_ABL & 2) ? u32x4{(uint32_t)(j + tpi), 3u, (uint32_t)C, 5u} : *reinterpret_cast<const u32x4*>(ws + tpi * U8_TAPB + wro[j]);
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if constexpr ((U8_ABL & 1) != 0) acc[C][rt][j][0] += __builtin_bit_cast(f32x4, wf[j])[0] * __builtin_bit_cast(f32x4, xf[rt])[1];
-          else mma16<H>(acc[C][rt][j], wf[j], xf[rt]);
+          for (int rt = 0; rt < 3; ++rt)
+            xf[rt] = (U8_ABL & (2 | 16)) ? u32x4{(uint32_t)(D + rt), 1u, 2u, 3u} : *reinterpret_cast<const u32x4*>(hs + abase[rt] + doff(D));
         }
+        u32x4 wf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          wf[j] = (U8_ABL & (2 | 32)) ? u32x4{(uint32_t)(j + tpi), 3u, (uint32_t)C, 5u} : *reinterpret_cast<const u32x4*>(ws + tpi * U8_TAPB + wro[j]);
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if constexpr ((U8_ABL & 1) != 0) acc[C][rt][j][0] += __builtin_bit_cast(f32x4, wf[j])[0] * __builtin_bit_cast(f32x4, xf[rt])[1];
+            else mma16<H>(acc[C][rt][j], wf[j], xf[rt]);
+          }
+      }
     };
     tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
-    tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
-    tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+    tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{});
   };
-  // end of a stage: everything but the loads issued at its start has landed (they are the newest NB vector-memory operations)
+  // end of a stage: everything but the newest NB vector-memory operations has landed
   auto stage_end = [&](auto NBC) __attribute__((always_inline)) {
     constexpr int NB = decltype(NBC)::value;
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NB) : "memory");
@@ -294,30 +302,30 @@ __global__ __launch_bounds__(U8_NTHR) void conv_up8_kernel(const ConvKArgs P, co
 
   // ---- epilogue of one tile: class c, lane = (voxel of row tile rt, channels (2 ch + j) * 16 + 4 q4 .. + 3) -------------------------
   const int ychunk = (q4 & 1) * 2 + (q4 >> 1);          // the 8-channel chunk (of the wave's 32 columns) a lane holds behind the swap
-  int ooff[2], aoff[2];
+  int ooff[3], aoff[3];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < 3; ++rt) {
     const int vox = va[rt] * G.oa + vb[rt] * G.ob + pc * G.oc;
     ooff[rt] = (vox * P.o_ld + ch * 32 + ychunk * 8) * 2;
     aoff[rt] = (vox * P.add_ld + ch * 32 + 4 * q4) * ASZ;
   }
   auto epilogue = [&](int n, int a0, int b0, int c0) {
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(P.out + (int64_t)n * G.out_sample_bytes, 0, G.out_sample_bytes, 0x00020000);
-    bool rv[2];
+    bool rv[3];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) rv[rt] = (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
+    for (int rt = 0; rt < 3; ++rt) rv[rt] = (a0 + va[rt] < G.da) && (b0 + vb[rt] < G.db) && (c0 + pc < G.dc);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const ctseg_conv_class& K = P.cls[c];
+    for (int c = 0; c < NCLS; ++c) {
+      const ctseg_conv_class& K = P.cls[u8_gclass(GRP, c)];
       const int cb = a0 * G.oa + b0 * G.ob + c0 * G.oc + (K.ox * P.Yo + K.oy) * P.Zo + K.oz;
       // the class's four addend pieces are requested together (buffer loads: out-of-range offsets for voxels the tile does not own),
       // so their round trips overlap instead of following one another
-      f32x4 ad[2][2];
+      f32x4 ad[3][2];
       if (P.add != nullptr) {
         const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.add) + (int64_t)n * G.add_sample_bytes, 0, G.add_sample_bytes, 0x00020000);
         const int asoff = cb * P.add_ld * ASZ;
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int vo = rv[rt] ? aoff[rt] + j * 16 * ASZ : (int)0x80000000;
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(U8_NTHR) void conv_up8_kernel(const ConvKArgs P, co
           }
       }
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < 3; ++rt) {
         u32x2 o2[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -355,26 +363,35 @@ __global__ __launch_bounds__(U8_NTHR) void conv_up8_kernel(const ConvKArgs P, co
     }
   };
 
-  // tile sequence: each XCD owns a contiguous range of tiles (neighbouring halos share that XCD's L2)
-  const int GX = gridDim.x;
+  // tile sequence: each XCD owns a contiguous range of tiles (neighbouring halos share that XCD's L2); both class groups walk the
+  // same sequence (workgroups sid and gxs + sid sit on the same XCD when gxs is a multiple of 8: the second reads the halo from L2)
+  const int GX = G.gxs;
   int first, stride, last;
   if ((GX & 7) == 0) {
-    const int chunk = (total_tiles + 7) / 8, xcd = blockIdx.x & 7;
-    first = xcd * chunk + (blockIdx.x >> 3);
+    const int chunk = (total_tiles + 7) / 8, xcd = sid & 7;
+    first = xcd * chunk + (sid >> 3);
     stride = GX >> 3;
     last = (xcd + 1) * chunk < total_tiles ? (xcd + 1) * chunk : total_tiles;
   } else {
-    first = blockIdx.x; stride = GX; last = total_tiles;
+    first = sid; stride = GX; last = total_tiles;
   }
 
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-  using N5 = std::integral_constant<int, 5>; using N8 = std::integral_constant<int, 8>;
-  int t = first, hcur = 0;
+  using N9 = std::integral_constant<int, 9>; using N12 = std::integral_constant<int, 12>;
+  // Stage S of the global sequence (3 per chunk, chunks of consecutive tiles back to back) lives in ring slot S % 5 and is requested at
+  // the start of stage S - 4; the halo chunk of chunk k + 1 is requested at the start of chunk k's first stage, AHEAD of that stage's
+  // weight request.  At the end of a stage the next one must have landed: the newest operations then are three weight requests
+  // (9 operations) plus, at the end of a chunk's first and second stage, the halo request (12); the end of a chunk's last stage also
+  // needs that halo: 9.
+  int t = first, hcur = 0, slot = 0;                   // slot of the stage about to be computed
+  auto slot_of = [&](int ahead) { const int s = slot + ahead; return s >= U8_SLOTS ? s - U8_SLOTS : s; };
   if (t < last) {
     halo_tile(t, true);
     issue_halo(0, 0);
-    issue_w(0, I0{});
-    issue_w(0, I1{});
+    issue_w(0, I0{}, 0);
+    issue_w(0, I1{}, 1);
+    issue_w(0, I2{}, 2);
+    issue_w(1, I0{}, 3);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -389,25 +406,35 @@ __global__ __launch_bounds__(U8_NTHR) void conv_up8_kernel(const ConvKArgs P, co
     zero_acc();
 #pragma unroll 1
     for (int kc = 0; kc < NKC; ++kc) {
-      const bool lastc = kc + 1 == NKC;
-      const int kcn = lastc ? 0 : kc + 1;
-      issue_w(kc, I2{});                              // two stages ahead: this chunk's last nine blocks
-      compute(I0{}, hcur);
-      stage_end(N5{});
-      issue_w(kcn, I0{});                             // the next chunk (of the next tile behind the last one)
-      if (lastc) halo_tile(tn, tn < last);
-      issue_halo(kcn, hcur ^ 1);
-      compute(I1{}, hcur);
-      stage_end(N8{});
-      issue_w(kcn, I1{});
-      compute(I2{}, hcur);
-      stage_end(N5{});
+      const int k1 = kc + 1 < NKC ? kc + 1 : kc + 1 - NKC, k2 = kc + 2 < NKC ? kc + 2 : kc + 2 - NKC;     // chunks of the stages 4 ahead (NKC >= 4)
+      // stage 0: the next chunk's halo (of the next tile behind the last chunk), then stage 3 kc + 4 = (k1, 1)
+      if (kc + 1 == NKC) halo_tile(tn, tn < last);
+      issue_halo(k1, hcur ^ 1);
+      issue_w(k1, I1{}, slot_of(4));
+      compute(I0{}, hcur, slot);
+      stage_end(N12{});
+      slot = slot_of(1);
+      issue_w(k1, I2{}, slot_of(4));                  // stage 3 kc + 5 = (k1, 2)
+      compute(I1{}, hcur, slot);
+      stage_end(N12{});
+      slot = slot_of(1);
+      issue_w(k2, I0{}, slot_of(4));                  // stage 3 kc + 6 = (k2, 0)
+      compute(I2{}, hcur, slot);
+      stage_end(N9{});
+      slot = slot_of(1);
       hcur ^= 1;
     }
     epilogue(n, a0, b0, c0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last prefetches (never read) land before the workgroup's LDS is released
   if (STATS && stat_n >= 0) flush_stats(stat_n);
+}
+
+template <typename H, bool STATS, bool ZXY>     // H = 16-bit storage kind (BF16 / F16)
+__global__ __launch_bounds__(U8_NTHR) void conv_up8_kernel(const ConvKArgs P, const Up8Geom G, int total_tiles) {
+  __shared__ __attribute__((aligned(16))) char smem[U8_TOTAL];
+  if ((int)blockIdx.x < G.gxs) conv_up8_body<H, STATS, ZXY, 0>(P, G, total_tiles, smem);     // (workgroup-uniform)
+  else conv_up8_body<H, STATS, ZXY, 1>(P, G, total_tiles, smem);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -433,6 +460,8 @@ static void up8_geom(const ConvKArgs& a, Up8Geom& g) {
   g.in_sample_bytes = (int)((int64_t)a.Xi * a.Yi * a.Zi * a.g_ld * 2);
   g.out_sample_bytes = (int)((int64_t)a.Xo * a.Yo * a.Zo * a.o_ld * 2);
   g.add_sample_bytes = (int)((int64_t)a.Xo * a.Yo * a.Zo * a.add_ld * (a.add_f32 ? 4 : 2));
+  const int total = g.tiles * a.N;
+  g.gxs = total < 128 ? total : 128;            // 2 x 128 workgroups = one per CU, the reference's 256 tiles twice each
 }
 
 bool conv_up8_eligible(const ConvKArgs& a, int dtype, int nclass) {
@@ -464,15 +493,11 @@ bool conv_up8_eligible(const ConvKArgs& a, int dtype, int nclass) {
   return taps == 27;
 }
 
-static int up8_grid(const ConvKArgs& a, const Up8Geom& g) {
-  const int total = g.tiles * a.N;
-  return total < 256 ? total : 256;
-}
-
+// InstanceNorm partial slots per sample: one per workgroup (both class groups)
 int conv_up8_slots(const ConvKArgs& a) {
   Up8Geom g;
   up8_geom(a, g);
-  return up8_grid(a, g);
+  return 2 * g.gxs;
 }
 
 void launch_conv_up8(ConvKArgs& a, hipStream_t st) {
@@ -480,7 +505,7 @@ void launch_conv_up8(ConvKArgs& a, hipStream_t st) {
   up8_geom(a, g);
   a.tiles = g.tiles;
   const int total = g.tiles * a.N;
-  const dim3 grid((unsigned)up8_grid(a, g)), blk(U8_NTHR);
+  const dim3 grid((unsigned)(2 * g.gxs)), blk(U8_NTHR);
   const bool stats = a.stats != nullptr;
   const bool zxy = g.pa == 2;
 #define CTSEG_U8_GO(H, ST)                                                                                        \
