@@ -28,7 +28,7 @@
 #include <type_traits>
 
 #ifndef U8_ABL
-#define U8_ABL 0     // timing-only ablation: 1 no MFMAs, 2 no LDS operand reads, 4 no weight stream, 8 no halo loads, 16 no x operand reads, 32 no weight operand reads
+#define U8_ABL 0     // timing-only ablation: 1 no MFMAs, 2 no LDS operand reads, 4 no weight stream, 8 no halo loads, 16 no x operand reads, 32 no weight operand reads, 64 no stage barriers, 128 no DMA instructions at all
 #endif
 
 namespace ctseg {
@@ -159,6 +159,7 @@ __device__ __forceinline__ void conv_up8_body(const ConvKArgs& P, const Up8Geom&
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int base = ((r == 2 && wave == 7) ? 512 : r * 512) + wave * 64;
+      if (U8_ABL & 128) continue;
       u8_raw_buffer_load_lds(h_rs, (u8_lds_u32_ptr)(sH + buf * U8_HBUF + base * 16), 16, h_v[r], h_soff + kc * 64, 0, 0);
     }
   };
@@ -187,6 +188,7 @@ __device__ __forceinline__ void conv_up8_body(const ConvKArgs& P, const Up8Geom&
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
       const int ge = (g == 2 && wave >= 4) ? 1 : g;
+      if (U8_ABL & 128) continue;
       u8_raw_buffer_load_lds(w_rs, (u8_lds_u32_ptr)(sW + slot * U8_STAGE + (wave * 64 + ge * 512) * 16), 16, w_v[s][g], kc * 64, 0, 0);
     }
   };
@@ -296,7 +298,7 @@ __device__ __forceinline__ void conv_up8_body(const ConvKArgs& P, const Up8Geom&
   auto stage_end = [&](auto NBC) __attribute__((always_inline)) {
     constexpr int NB = decltype(NBC)::value;
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NB) : "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(U8_ABL & 64)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
 
