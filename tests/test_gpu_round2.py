@@ -436,6 +436,8 @@ def test_native_adam_state_checkpoint_round_trip_on_gpu():
     ("conv", 64, 64, (1, 9, 20, 13), "streamed-weight halo"),
     ("convT", 128, 32, (1, 8, 16, 16), "streamed-weight halo, 8 classes"),
     ("convT", 64, 10, (1, 8, 8, 8), "up halo"),
+    ("convT", 384, 64, (1, 10, 18, 12), "many-channel 8-class (conv_up8), forward"),
+    ("conv_s2", 64, 256, (1, 36, 40, 12), "many-channel 8-class (conv_up8), input gradient"),
     ("conv_s2", 32, 128, (1, 18, 40, 24), "stride-2 halo"),
     ("conv_s2", 1, 32, (1, 16, 16, 8), "stem"),
     ("conv1", 128, 256, (1, 6, 6, 4), "1x1x1 residual"),
