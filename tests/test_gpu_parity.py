@@ -714,3 +714,45 @@ def test_loss_dice_summary_kernel_matches_the_torch_expressions():
     assert abs(float(loss) - float(want_loss)) <= 1e-6 * abs(float(want_loss))
     assert torch.allclose(dpc.cpu(), want_pc.cpu(), rtol=1e-6, atol=1e-7) and float(dpc[2]) == 0.0
     assert abs(float(dm) - float(want_mean)) <= 1e-6
+
+
+def test_many_channel_8_class_kernel_statistics_and_addend():
+    """conv_up8_kernel's two extras, at op level: the InstanceNorm partial sums of the forward pass (one slot per workgroup and class
+    group; their total = sum / sum of squares of the fp32 results over the voxels) and the addend of the input-gradient pass
+    (dx = g + dgrad(dy), what the dense skip gradient uses).  Ragged 3 x 8 x 8 tiles, two samples."""
+    from capstone_amd.engine import GemmLayer
+    from helpers import MiniPlan, from_cl, rel_err, to_cl
+    torch.manual_seed(5)
+    mod = torch.nn.ConvTranspose3d(256, 64, 3, 2, 1, output_padding=1)
+    x = torch.randn(2, 256, 10, 18, 12)
+    with torch.no_grad():
+        yref = mod(x)                      # (MiniPlan moves the parameters to the device)
+    plan = MiniPlan([mod.weight, mod.bias], DEV, BF16, 3)
+    xa = to_cl(x, BF16, DEV)
+    layer = GemmLayer(plan, "t", True, 3, 2, 256, [(mod.weight, mod.bias, 64)], 256)
+    plan.packer.finalize()
+    y, stats = layer.emit_fwd(xa, want_stats=True)
+    plan.run()
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(y, False), yref) < 2.5e-2
+    part = stats.partials.cpu()
+    assert rel_err(part[:, :, 0, :64].sum(1), yref.sum(dim=(2, 3, 4))) < 2.5e-2
+    assert rel_err(part[:, :, 1, :64].sum(1), (yref * yref).sum(dim=(2, 3, 4))) < 2.5e-2
+
+    mod2 = torch.nn.Conv3d(64, 256, 3, 2, 1)
+    x2 = torch.randn(2, 64, 20, 36, 12)
+    xr = x2.clone().requires_grad_(True)
+    y2 = mod2(xr)
+    gy = torch.randn_like(y2)
+    y2.backward(gy)
+    addend = torch.randn_like(x2)
+    plan2 = MiniPlan([mod2.weight, mod2.bias], DEV, BF16, 3)
+    layer2 = GemmLayer(plan2, "t", False, 3, 2, 64, [(mod2.weight, mod2.bias, 256)], 64)
+    plan2.packer.finalize()
+    layer2.emit_fwd(to_cl(x2, BF16, DEV))         # (records the input geometry the backward passes use)
+    ga, aa = to_cl(gy, BF16, DEV), to_cl(addend, BF16, DEV)
+    gxa = layer2.emit_dgrad(ga, add=aa)
+    plan2.run()
+    torch.cuda.synchronize()
+    ref = xr.grad + addend.bfloat16().float()
+    assert rel_err(from_cl(gxa, False), ref) < 2.5e-2
