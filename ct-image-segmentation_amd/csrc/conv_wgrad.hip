@@ -418,8 +418,10 @@ __global__ __launch_bounds__(32 * NSUB) void wgrad_reduce_kernel(const float* __
 // combined in fixed order; ceil(rows * ceil(nb / 4) / 8) blocks.  (The scalar kernel above moves 128 B per half wave with 8
 // sub-sums: 1 - 1.5 TB/s on the 30 - 67 MB of slabs of a persistent LDS-halo weight-gradient kernel, 12 + 6 launches per step of
 // the reference's network.)  col0 a multiple of 4; columns nb .. roundup(nb, 4) are pad columns of the slab (read, not written).
+// <= 32 registers (modest unrolling): a block then fits beside the persistent one-workgroup-per-CU halo kernels of the main stream
+// (2 x 240 of a SIMD's 512 registers, <= 154 KB of LDS) instead of waiting for them to end; same summation order.
 template <int LW, int NSUB>      // LW lanes x float4 along a slab row, NSUB strided sub-sums: (8, 32) for many slabs, (32, 8) for few
-__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ ws, int nslabs, int kpad_w, int cn_pad, int A, int AS, int T,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void wgrad_reduce4_kernel(const float* __restrict__ ws, int nslabs, int kpad_w, int cn_pad, int A, int AS, int T,
                                                             int col0, int nb, float* __restrict__ dw, float* __restrict__ db) {
   static_assert(LW * NSUB == 256, "256 threads");
   __shared__ f32x4 s_part[NSUB][LW];
@@ -431,14 +433,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restr
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i4 < total4) {
     const float* p = ws + (int64_t)k * cn_pad + col0 + b0;
-#pragma unroll 4
+#pragma unroll 2
     for (int q = sub; q < nslabs; q += NSUB) s += *reinterpret_cast<const f32x4*>(p + q * slab);
   }
   s_part[sub][el] = s;
   __syncthreads();
   if (sub == 0 && i4 < total4) {
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 4
     for (int q = 0; q < NSUB; ++q) t += s_part[q][el];
     if (k == T * AS) {
       if (db != nullptr)
