@@ -69,22 +69,64 @@ def find_op(plan, name_sub, cin, cout):
     return None
 
 
-def cpu_baseline(shape, threads):
-    """the oracle (torch CPU restatement of the reference step) on the host cores: kind = "port"."""
+def cpu_baseline(shape, threads, device=None, precision="bf16"):
+    """the oracle (torch CPU restatement of the reference step) on the host cores: kind = "port".  The same step — same seeded
+    weights, same seeded volume — then runs once on the device in the benchmark's storage dtype (and in fp32): BASELINE.json's
+    "Dice vs ref" (second return value; the oracle computes its Dice inside the timed step anyway)."""
     from oracle.trainer import OracleUNet3D
     torch.set_num_threads(threads)
     torch.manual_seed(SEED)
     m = OracleUNet3D(filters=FILTERS, loss_fx=("CrossEntropy",))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
     opt = m.configure_optimizers()
     B, H, W, D = shape
     batch = synthetic_batch(B, H, W, D, "cpu", SEED)
     t0 = time.time()
-    m.fit_step(batch, opt)
+    oloss = m.fit_step(batch, opt)
     dt = time.time() - t0
     frac = B * H * W * D / float(512 * 512 * 48)     # 512x512x48 volumes' worth of voxels in the sample
-    return {"value": frac / dt, "unit": "volumes/s", "cores": threads, "kind": "port",
+    base = {"value": frac / dt, "unit": "volumes/s", "cores": threads, "kind": "port",
             "sample": f"1 training step (fwd+loss+Dice+bwd+Adam) of the oracle on {B}x1x{H}x{W}x{D} fp32 "
                       f"(= {frac:.3f} of a 512x512x48 volume), {dt:.1f} s on {threads} threads"}
+    dice = None
+    if device is not None:
+        from capstone_amd.volumetric.base_trainer import BaseUNet3D
+        odice = float(m.logged["Mean Dice Score (train)"])
+        oloss = float(m.logged["CrossEntropy Loss (train)"])
+        dice = {"shape": [B, 1, H, W, D], "seed": SEED, "oracle_dice": odice, "oracle_loss": oloss,
+                "what": "mean Dice (9 structures, NaN-aware batch mean) and cross-entropy of ONE training step from the same seeded "
+                        "weights on the same seeded synthetic volume: torch-CPU oracle (fp32) vs the HIP step; north_star bar +-0.002"}
+        dbatch = tuple(t.to(device) for t in batch)
+        for prec in dict.fromkeys((precision, "fp32")):
+            g = BaseUNet3D(filters=list(FILTERS), loss_fx=["CrossEntropy"], precision=prec, batch_size=B)
+            g.load_state_dict(sd)
+            g.to(device)
+            gl = float(g.fit_step(dbatch, keep_logits=False))
+            gd = float(g.logged["Mean Dice Score (train)"])
+            key = "" if prec == precision else "_fp32"
+            dice["dice" + key], dice["abs_diff" + key], dice["loss" + key] = gd, abs(gd - odice), gl
+            dice["dtype" + key] = prec
+            del g
+        torch.cuda.empty_cache()
+    return base, dice
+
+
+def host_enqueue(model, batch, steps=10):
+    """host side of one step: the recorded program is replayed by a Python loop over ctypes calls (no hipGraph).  Wall time of
+    ``steps`` fit_step calls WITHOUT a device synchronize (the queue holds them: 10 steps = ~1400 launches) against the same with
+    one — if the first approaches the second the step is launch-bound on the host."""
+    plan = model.unet.engine().last_plan
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.fit_step(batch, keep_logits=False)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    n_launch = len(plan.fwd) + len(plan.bwd)
+    return {"enqueue_ms_per_step": (t1 - t0) / steps * 1e3, "device_ms_per_step": (t2 - t0) / steps * 1e3,
+            "recorded_ops_per_step": n_launch, "steps": steps,
+            "note": "recorded C-ABI calls of the forward + backward programs; loss / Adam / re-layout / bookkeeping add ~10 more launches"}
 
 
 def fp32_line(model, batch, steps):
@@ -262,6 +304,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_v = float(loss.item())
+    if probe_i is not None:
+        plan.run = orig_run          # the event brackets belong to the timed region only
 
     baseline_shape = (B, H, W, D) == (2, 512, 512, 48)
     if rank == 0:
@@ -293,13 +337,16 @@ def main():
             flop = 2.0 * n_ * x_ * y_ * z_ * 256 * 256 * 27
             peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
             ach = flop / (kms * 1e-3) / 1e12
-            traffic = None     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this very kernel
+            # HBM bytes per launch are NOT measured in this run (PMC counters need rocprofv3): "traffic" stays null here and the
+            # figure of the committed rocprofv3 --pmc passes of this very kernel is quoted under its own name, with its source
+            traffic_committed, pmc_src = None, None
             pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("pmc_bottleneck.json"))
             pmc = os.path.join(ROOT, "profiles", pmc[-1]) if pmc else ""
             if args.precision == "bf16" and (B, H, W, D) == (2, 512, 512, 48) and os.path.exists(pmc):
-                traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+                traffic_committed, pmc_src = json.load(open(pmc))["traffic_bytes_per_launch"], os.path.relpath(pmc, ROOT)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                               "traffic": traffic, "kernel": "conv_igemm_ring_kernel (192x256 tile, bf16) encoder-bottleneck Conv3d 256->256 k3",
+                               "traffic": None, "traffic_from_committed_pmc_profile": traffic_committed,
+                               "traffic_source": pmc_src, "kernel": "conv_igemm_ring_kernel (192x256 tile, bf16) encoder-bottleneck Conv3d 256->256 k3",
                                "launch_ms": kms, "launch_ms_minus_event_pair": raw - ovh, "event_pair_ms": ovh,
                                "flop_per_launch": flop, "launches_timed": len(ev)}
             if baseline_shape:
@@ -314,7 +361,10 @@ def main():
                 ncpu = len(os.sched_getaffinity(0))
             except AttributeError:
                 ncpu = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_baseline(tuple(args.cpu_shape), max(1, min(ncpu, 16)))
+            out["cpu_baseline"], dvr = cpu_baseline(tuple(args.cpu_shape), max(1, min(ncpu, 16)), dev, args.precision)
+            out["config"]["dice_vs_ref"] = dvr
+        if world == 1:
+            out["config"]["host"] = host_enqueue(model, batch)
         if world == 1 and args.fp32_steps > 0 and args.precision == "bf16":
             out["config"]["fp32"] = fp32_line(model, batch, args.fp32_steps)
         if world == 1 and args.drop_in_steps > 0:

@@ -681,6 +681,10 @@ class Packer:
         """True when refresh(part="first") / refresh(part="rest") can rebuild the first forward pass's operands on their own"""
         return self.pack_blocks is not None and getattr(self, "n_first_rows", 0) > 0
 
+    def stale(self):
+        """True when refresh() (no force) would rebuild the operands: the parameters changed since the last complete re-layout"""
+        return self.dirty or self.plan.store.version() != self.version
+
     def refresh(self, force=False, part=None):
         """part: None = everything; "first" = the biases and the packed operands of the first forward pass; "rest" = the others
         (the pair, in that order, equals None)"""

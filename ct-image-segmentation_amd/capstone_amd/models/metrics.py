@@ -25,5 +25,6 @@ class DiceMetricWrapper(object):
             p = input.reshape(B, -1).to(torch.uint8).contiguous()
             t = target.reshape(B, -1).to(torch.uint8).contiguous()
             cnt = segloss.dice_counts(p, t, self.n_classes)
+        self.last_counts = cnt      # (B, 3, C) int64: what epoch_dice_across_ranks gathers at N > 1
         eng = segloss.SegLossEngine.__new__(segloss.SegLossEngine)
         return segloss.SegLossEngine.dice_metric(eng, cnt)

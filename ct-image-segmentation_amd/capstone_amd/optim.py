@@ -21,10 +21,16 @@ class Adam(torch.optim.Adam):
                         and not g[0].get("differentiable", False))
 
     # ---- which parameters are the engine's -----------------------------------------------------------------------
-    def _store(self):
+    def _store(self, ensure=False):
         if not self._native:
             return None
         eng = self._unet.engine()
+        if ensure:
+            # no flat store yet (a fresh module whose optimizer state is loaded before its first forward — torch's usual resume
+            # order), or the Parameters were re-homed since: build / re-attach it where the parameters live now
+            own = next(iter(self._unet.parameters()), None)
+            if own is not None:
+                eng.ensure(own.device)
         st = eng.store
         if st is None or not st.attached():
             return None
@@ -84,7 +90,7 @@ class Adam(torch.optim.Adam):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        st = self._store()
+        st = self._store(ensure=True)
         if st is None:
             return
         have = [p for p in st.params if p in self.state and "exp_avg" in self.state[p]]

@@ -538,8 +538,18 @@ class Plan:
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
             self._repack_ev = None
+        if self.packer.stale():
+            # the parameters changed since repack_after_update queued its two-part re-layout (load_state_dict, a broadcast, a
+            # foreign optimizer): refresh() is about to rewrite the packed buffer on THIS stream while the side stream's "rest" part
+            # may still be reading the flat buffer and writing the same operands — order it behind that part first
+            ev2 = getattr(self, "_repack_ev2", None)
+            if ev2 is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev2)
+                self._repack_ev2 = None
         self.packer.refresh()
         self.fwd_gen += 1
+        # a d loss / d logits left by a fused loss whose backward never ran (skipped step, exception) belongs to the OLD batch
+        self.dlogits_is_current = False
         end = len(self.fwd) - 1 if skip_head else None
         ev2 = getattr(self, "_repack_ev2", None)
         if ev2 is not None:
@@ -651,7 +661,9 @@ class Engine:
         self.device = None
         self.plans = {}
         self.last_plan = None
+        self.reducer = None            # capstone_amd.distributed.GradAllReducer once the module is data-parallel (attach())
         self._warned_fp16_train = False
+        self._warned_unattached = False
 
     def train_dt(self):
         """storage dtype of the TRAINING plans.  A model built with Lightning's ``--precision 16`` (IEEE half) runs its inference
@@ -667,6 +679,21 @@ class Engine:
                           "precision='bf16' to use one storage dtype throughout.", RuntimeWarning, stacklevel=3)
             self._warned_fp16_train = True
         return BF16
+
+    def warn_if_unattached(self):
+        """a process group with several ranks exists but nobody made this model data-parallel: every rank then trains on its own
+        gradients and the replicas drift apart without an error.  Said once per engine; ``CTSEG_LOCAL_GRADS=1`` silences it
+        (rank-local warm-up steps, independent replicas)."""
+        if self._warned_unattached or os.environ.get("CTSEG_LOCAL_GRADS") == "1":
+            return
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            import warnings
+            warnings.warn("torch.distributed runs with %d ranks but this model was not made data-parallel: gradients stay "
+                          "rank-local. Call capstone_amd.distributed.attach(module) (Lightning: configure_ddp does it); a stock "
+                          "DistributedDataParallel wrap cannot average gradients that the HIP kernels write into the flat buffer."
+                          % dist.get_world_size(), RuntimeWarning, stacklevel=3)
+            self._warned_unattached = True
 
     def _param_order(self):
         """backward (gradient-readiness) order: up path of the top level first, stem last"""
@@ -693,6 +720,13 @@ class Engine:
             self.device = device
             self.store = ParamStore(self._param_order(), device)
             self.plans = {}
+            if self.reducer is not None:
+                # a data-parallel module changed device: the exchange follows the new flat gradient buffer (split points are
+                # computed per plan from its own readiness marks)
+                from . import distributed as cdist
+                red = self.reducer
+                self.reducer = cdist.GradAllReducer(self.store.flat_g, self.store.n, None,
+                                                    {self.store.off(p): p.numel() for p in self.store.params}, red.group, red.always)
             if old is not None and old.step > 0 and old.adam_m is not None and old.n == self.store.n:
                 # the module changed device with optimizer state in the old store (a checkpoint loaded on the CPU, then .to(cuda);
                 # Lightning calls on_load_checkpoint before it moves the module): Adam's moments and step count move with it.
@@ -832,6 +866,18 @@ class _GradHandOff:
         self.kept = None
 
 
+def _backward_with_exchange(engine, plan):
+    """run the recorded backward program; when the engine carries a gradient reducer (distributed.attach) the readiness hooks
+    fire the chunked all-reduce from inside it.  Returns the scale that turns the summed flat gradient into the mean."""
+    reducer = engine.reducer
+    if reducer is not None:
+        plan.backward(reducer.hooks(plan))
+        return reducer.finish()
+    engine.warn_if_unattached()
+    plan.backward()
+    return 1.0
+
+
 class _StepLossFn(torch.autograd.Function):
     """The scalar loss of a training step whose forward ALREADY ran the loss and wrote d loss / d logits for an upstream gradient of
     1 into the plan (fused head: the logits convolution + cross-entropy in one launch; or the one-pass fused cross-entropy over
@@ -858,14 +904,7 @@ class _StepLossFn(torch.autograd.Function):
         gs = g.detach().to(device=dl.device, dtype=torch.float32).contiguous()
         nat.call("ctseg_scale_inplace", dl.data_ptr(), plan.dt, dl.numel(), gs.data_ptr(), 1.0)
         hand = _GradHandOff(engine.store)
-        reducer = getattr(module, "reducer", None)
-        if reducer is not None:
-            plan.backward(reducer.hooks(plan))
-            scale = reducer.finish()
-        else:
-            plan.backward()
-            scale = 1.0
-        hand.publish(scale)
+        hand.publish(_backward_with_exchange(engine, plan))
         return (None, None, None, None) + (None,) * len(ctx.engine.store.params)
 
 
@@ -893,8 +932,10 @@ class _UNetFn(torch.autograd.Function):
             plan.dlogits.t[..., :C].copy_(gv.permute(0, 2, 3, 4, 1))
         plan.dlogits_is_current = False
         hand = _GradHandOff(engine.store)        # p.grad becomes a view of the flat gradient buffer: no per-parameter copies
-        plan.backward()
-        hand.publish()
+        # data-parallel (distributed.attach): the same exchange as fit_step / _StepLossFn — every loss.backward() leaves the MEAN
+        # gradient over the ranks in p.grad, as Lightning's DDP does (capstone/volumetric/base_trainer.py:196,217), whichever loss
+        # recipe or entry point (training_step with Dice / Focal / GDL, forward() + a custom loss) led here
+        hand.publish(_backward_with_exchange(engine, plan))
         grads = [None] * len(engine.store.params)
         gx = None
         if ctx.needs_input_grad[0]:

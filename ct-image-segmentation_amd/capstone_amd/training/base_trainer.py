@@ -17,11 +17,11 @@ import torch
 
 from .. import STRUCTURES
 from ..models import DiceMetricWrapper, MultipleLossWrapper, UNet
-from ..volumetric.base_trainer import _Base, _precision, pl
+from ..volumetric.base_trainer import _Base, _DataParallelSurface, _precision, pl
 from .utils import _squash_masks, _squash_predictions
 
 
-class BaseUNet2D(_Base):
+class BaseUNet2D(_DataParallelSurface, _Base):
     def __init__(self, filters: List = [64, 128, 256, 512, 1024], use_res_units: bool = False, downsample: bool = False,
                  lr: float = 1e-3, loss_fx: list = ["Focal", "Dice"], exclude_missing: bool = False, **kwargs) -> None:
         super().__init__()
@@ -92,6 +92,7 @@ class BaseUNet2D(_Base):
                 pred[:, 1:] = pred[:, 1:] * mask_indicator[:, :, None, None]
             pred = _squash_predictions(pred)
             dice_mean, dice_per_class = self.dice_score(pred, masks)
+            self._keep_dice_counts(self.dice_score.last_counts, prefix)
             for structure, score in zip(STRUCTURES, dice_per_class):
                 self.log(f"{structure} Dice ({prefix})", score, on_step=False, on_epoch=True)
             self.log(f"Mean Dice Score ({prefix})", dice_mean, on_step=False, on_epoch=True)

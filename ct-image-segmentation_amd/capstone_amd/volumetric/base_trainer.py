@@ -91,6 +91,70 @@ except Exception:  # noqa: BLE001
 SEED = 12342
 
 
+class _DataParallelSurface:
+    """What both drop-in modules (BaseUNet3D, BaseUNet2D) need so that the reference's ONLY way into multi-GPU training —
+    ``Trainer.from_argparse_args(args)`` with ``--gpus N --distributed_backend ddp`` (capstone/volumetric/base_trainer.py:196,217;
+    capstone/training/base_trainer.py: the same Trainer flags) — lands on the engine's own gradient exchange."""
+
+    # ---- the gradient reducer lives on the engine (plan.Engine.reducer): one object for every route into the backward ----
+    @property
+    def reducer(self):
+        return self.unet.engine().reducer
+
+    @reducer.setter
+    def reducer(self, value):
+        self.unet.engine().reducer = value
+
+    def configure_ddp(self, model, device_ids):
+        """Lightning 1.0 hook (``LightningModule.configure_ddp(model, device_ids)``, called by the DDP accelerator once the process
+        group exists and the module sits on its GPU; stock: ``LightningDistributedDataParallel(model, device_ids, ...)``).  Here:
+        build the flat parameter store on the module's device, make the replicas identical and install the flat-buffer gradient
+        exchange (``distributed.attach``), and return a pass-through wrapper with DDP's ``.module`` / per-mode ``forward``."""
+        from .. import distributed as cdist
+        dev = next(model.unet.parameters()).device
+        model.unet.engine().ensure(dev)
+        cdist.attach(model)
+        return cdist.NativeDataParallel(model, device_ids)
+
+    @property
+    def _ddp_params_and_buffers_to_ignore(self):
+        """torch's ``DistributedDataParallel.__init__`` probes the wrapped module for this attribute: the probe is the tripwire.
+        A stock DDP wrap would train on rank-local gradients without any error (its reducer waits for AccumulateGrad hooks that
+        never fire: the HIP kernels write the flat gradient buffer and the autograd nodes return None for the parameters)."""
+        raise nat.NativeError(
+            "torch.nn.parallel.DistributedDataParallel cannot wrap this module: its gradients are written into one flat buffer by "
+            "the HIP backward kernels and averaged by capstone_amd.distributed.attach(module). Under Lightning the module's own "
+            "configure_ddp() does that; in a hand-written loop call attach(module) after init_process_group and skip the DDP wrap.")
+
+    # ---- Dice across ranks (SURVEY.md §8e: the integer counts, one small all-gather at epoch end) -------------------------
+    def _keep_dice_counts(self, cnt, prefix):
+        """remember this step's per-sample integer Dice counts (B, 3, C) when the module is data-parallel (or on request,
+        ``CTSEG_KEEP_DICE_COUNTS=1``): 30 int64 per sample and step"""
+        import os
+        red = self.unet.engine().reducer
+        if (red is not None and red.world > 1) or os.environ.get("CTSEG_KEEP_DICE_COUNTS") == "1":
+            self.__dict__.setdefault("_dice_counts", {}).setdefault(prefix, []).append(cnt.detach().clone())
+
+    def epoch_dice_across_ranks(self, prefix="train", reset=True, group=None):
+        """(mean Dice, per-class Dice (9,)) of the epoch as the reference computes it on the GLOBAL batch: per step, the
+        per-sample counts of all ranks are one batch for ``compute_meandice`` + ``do_metric_reduction("mean_batch")``
+        (capstone/models/temp.py:173-292, capstone/models/metrics.py:15-21); the epoch value is the mean over the steps
+        (Lightning's ``on_epoch=True``).  The reference itself logs per rank (no ``sync_dist``, :106-109,125-131); this is the
+        figure "Dice vs ref" is read from at N > 1.  One all-gather of (steps, B, 3, C) int64.  None when nothing was kept."""
+        from .. import distributed as cdist
+        kept = self.__dict__.get("_dice_counts", {}).get(prefix)
+        if not kept:
+            return None
+        cnt = cdist.gather_dice_counts(torch.stack(kept), group)          # (steps, world * B, 3, C)
+        if reset:
+            self._dice_counts[prefix] = []
+        eng = segloss.SegLossEngine.__new__(segloss.SegLossEngine)
+        per_step = [segloss.SegLossEngine.dice_metric(eng, c) for c in cnt]
+        mean = torch.stack([m for m, _ in per_step]).mean()
+        per_class = torch.stack([p for _, p in per_step]).mean(dim=0)
+        return mean, per_class
+
+
 def _precision(kwargs):
     """Lightning's Trainer flag arrives through **vars(args) too.  ``--precision 16`` is IEEE half, as in the reference's stack
     (Lightning 1.0 native AMP): fp16 STORAGE for the inference passes (validation / test / sliding window), and bf16 storage
@@ -106,7 +170,7 @@ def _precision(kwargs):
     raise ValueError(f"unsupported precision {p!r}")
 
 
-class BaseUNet3D(_Base):
+class BaseUNet3D(_DataParallelSurface, _Base):
     def __init__(self, filters: List = [16, 32, 64, 128, 256], use_res_units: bool = False, downsample: bool = False,
                  lr: float = 1e-3, loss_fx: list = ["CrossEntropy"], exclude_missing: bool = False, **kwargs) -> None:
         super().__init__()
@@ -121,7 +185,6 @@ class BaseUNet3D(_Base):
         self.unet = self._construct_model()
         self.loss_func = MultipleLossWrapper3D(losses=loss_fx, exclude_missing=exclude_missing)
         self.dice_score = DiceMetricWrapper3D()
-        self.reducer = None      # capstone_amd.distributed.GradAllReducer when data-parallel
 
     @property
     def _n_classes(self):
@@ -214,6 +277,7 @@ class BaseUNet3D(_Base):
         eng, plan, le, weighted = self._forward_and_ce(batch, keep_logits=os.environ.get("CTSEG_DROPIN_KEEP_LOGITS", "0") == "1")
         plan.dlogits_is_current = True
         loss = self._log_ce_summary(le, weighted)
+        self._keep_dice_counts(le.cnt, "train")
         return _StepLossFn.apply(loss, eng, plan, self, *eng.store.params)
 
     def validation_step(self, batch, batch_idx=0):
@@ -245,6 +309,7 @@ class BaseUNet3D(_Base):
         with torch.no_grad():
             eng = getattr(prediction._ctseg_plan, "_ctseg_loss", None)
             dice_mean, dice_per_class = eng.dice_metric()
+            self._keep_dice_counts(eng.cnt, prefix)
             for structure, score in zip(STRUCTURES, dice_per_class):
                 self.log(f"{structure} Dice ({prefix})", score, on_step=False, on_epoch=True)
             self.log(f"Mean Dice Score ({prefix})", dice_mean, on_step=False, on_epoch=True)
@@ -298,10 +363,14 @@ class BaseUNet3D(_Base):
             book["total"] = torch.stack([vals[n] for n in names]).sum()
             book["dice"] = le.dice_metric()
 
-        if self.reducer is not None:
-            plan.backward(self.reducer.hooks(plan), before_join=bookkeeping)
-            scale = self.reducer.finish()
+        self._keep_dice_counts(le.cnt, "train")        # (queued before the next step overwrites the counters)
+
+        reducer = eng.reducer
+        if reducer is not None:
+            plan.backward(reducer.hooks(plan), before_join=bookkeeping)
+            scale = reducer.finish()
         else:
+            eng.warn_if_unattached()
             plan.backward(before_join=bookkeeping)
             scale = 1.0
         eng.store.adam_step(self.hparams.lr, betas, eps, grad_scale=scale)

@@ -518,8 +518,7 @@ bool conv_down_halo_eligible(const ConvKArgs& a, int dtype, int nclass) {
 }
 
 static int down_grid(const ConvKArgs& a, const DownGeom& g) {
-  const int total = g.tiles * a.N;
-  return total < 256 ? total : 256;
+  return persistent_grid(CTSEG_NUM_CU, g.tiles * a.N);
 }
 
 int conv_down_halo_slots(const ConvKArgs& a) {

@@ -280,8 +280,7 @@ bool conv_down_r_eligible(const ConvKArgs& a, int dtype, int nclass) {
 }
 
 static int down_r_grid(const ConvKArgs& a, const DownRGeom& g) {
-  const int total = g.tiles * a.N;
-  return total < 256 ? total : 256;
+  return persistent_grid(CTSEG_NUM_CU, g.tiles * a.N);
 }
 
 int conv_down_r_slots(const ConvKArgs& a) {

@@ -350,8 +350,7 @@ int conv_halo_tiles(const ConvKArgs& a) {
 
 template <int VB, int NT> static int halo_grid(int total) {
   const int per_cu = HaloCfg<VB, NT>::TOTAL > 80 * 1024 ? 1 : (HaloCfg<VB, NT>::TOTAL > 54000 ? 2 : 3);   // 160 KiB LDS per CU
-  const int gx = 256 * per_cu;
-  return gx > total ? total : gx;
+  return persistent_grid(CTSEG_NUM_CU * per_cu, total);
 }
 
 // workgroups (= InstanceNorm partial slots per sample) a launch with this geometry uses

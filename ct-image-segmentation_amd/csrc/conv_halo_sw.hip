@@ -676,8 +676,7 @@ bool conv_halo_sw_eligible(const ConvKArgs& a, int dtype, int nclass) {
 }
 
 static int sw_grid(const ConvKArgs& a, const SwGeom& g) {
-  const int total = g.tiles * a.N;
-  return total < 256 ? total : 256;
+  return persistent_grid(CTSEG_NUM_CU, g.tiles * a.N);
 }
 
 int conv_halo_sw_slots(const ConvKArgs& a) {

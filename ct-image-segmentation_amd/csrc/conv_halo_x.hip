@@ -1110,8 +1110,7 @@ static int x_grid(const ConvKArgs& a) {
   // LDS: 2 x 41.5 KB of halo (+ 27 / 54 KB of weight fragments) per workgroup at 64-byte voxels: one workgroup per CU;
   // 2 x 20.7 KB at 32-byte voxels with the 15 weight fragments of 16 columns in registers: two per CU
   const int per_cu = (vb == 64 || a.Cn > 16) ? 1 : 2;
-  const int gx = 256 * per_cu;
-  return gx > total ? total : gx;
+  return persistent_grid(CTSEG_NUM_CU * per_cu, total);
 }
 
 int conv_halo_x_slots(const ConvKArgs& a) { return x_grid(a); }
@@ -1215,8 +1214,7 @@ bool conv_halo_x_ce_eligible(const ConvKArgs& a, int dtype, int nclass, int C) {
 }
 
 static int x_grid_ce(const ConvKArgs& a) {     // 48 KB of LDS but ~230 registers per lane (weights + the softmax's arrays): two workgroups per CU
-  const int total = x_tiles(a) * a.N, gx = 256 * 2;
-  return gx > total ? total : gx;
+  return persistent_grid(CTSEG_NUM_CU * 2, x_tiles(a) * a.N);
 }
 
 int conv_halo_x_ce_slots(const ConvKArgs& a) { return x_grid_ce(a); }

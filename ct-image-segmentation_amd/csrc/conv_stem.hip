@@ -251,7 +251,7 @@ bool conv_stem_eligible(const ConvKArgs& a, int dtype, int nclass) {
 }
 
 static int stem_tiles(int Xr, int Yr, int Zr) { return ((Xr + 3) / 4) * ((Yr + 7) / 8) * ((Zr + 7) / 8); }
-static int stem_grid(int total) { return total < 1024 ? total : 1024; }
+static int stem_grid(int total) { return persistent_grid(4 * CTSEG_NUM_CU, total); }
 int conv_stem_slots(const ConvKArgs& a) { return stem_grid(stem_tiles(a.Xr, a.Yr, a.Zr) * a.N); }
 
 void launch_conv_stem(ConvKArgs& a, hipStream_t st) {
@@ -518,8 +518,7 @@ bool wgrad_stem_eligible(const ctseg_wgrad_desc* d) {
 }
 
 static int wgrad_stem_grid(const ctseg_wgrad_desc* d) {
-  const int total = stem_tiles(d->Xr, d->Yr, d->Zr) * d->N;
-  return total < 512 ? total : 512;
+  return persistent_grid(2 * CTSEG_NUM_CU, stem_tiles(d->Xr, d->Yr, d->Zr) * d->N);
 }
 int wgrad_stem_slabs(const ctseg_wgrad_desc* d) { return 4 * wgrad_stem_grid(d); }
 

@@ -463,7 +463,7 @@ static void up8_geom(const ConvKArgs& a, Up8Geom& g) {
   g.out_sample_bytes = (int)((int64_t)a.Xo * a.Yo * a.Zo * a.o_ld * 2);
   g.add_sample_bytes = (int)((int64_t)a.Xo * a.Yo * a.Zo * a.add_ld * (a.add_f32 ? 4 : 2));
   const int total = g.tiles * a.N;
-  g.gxs = total < 128 ? total : 128;            // 2 x 128 workgroups = one per CU, the reference's 256 tiles twice each
+  g.gxs = persistent_grid(CTSEG_NUM_CU / 2, total);   // 2 x 128 workgroups = one per CU, the reference's 256 tiles twice each
 }
 
 bool conv_up8_eligible(const ConvKArgs& a, int dtype, int nclass) {

@@ -390,8 +390,7 @@ int conv_up_tiles(const ConvKArgs& a) { return ((a.Xr + 3) / 4) * ((a.Yr + 7) / 
 
 static int up_grid(const ConvKArgs& a) {
   const int total = conv_up_tiles(a) * a.N;
-  const int gx = (a.Cg * 2 == 128) ? 256 : 512;
-  return gx < total ? gx : total;
+  return persistent_grid((a.Cg * 2 == 128) ? CTSEG_NUM_CU : 2 * CTSEG_NUM_CU, total);
 }
 // InstanceNorm partial slots per sample: one per workgroup
 int conv_up_slots(const ConvKArgs& a) { return up_grid(a); }

@@ -642,8 +642,7 @@ static int wgrad_halo_grid(const ctseg_wgrad_desc* d) {
   // ONE 8-wave workgroup per CU for the head kernel: alone it is slower that way (0.43 -> 0.50 ms), inside the step — it runs on the
   // side stream beside the main stream's HBM-bound head passes — faster: 9.94 / 9.90 -> 9.86 / 9.82 ms/step (same box, round 2)
   if (const char* e = getenv("CTSEG_WH_PER_CU")) per_cu = atoi(e);
-  int g = 256 * per_cu;
-  return g < tiles ? g : tiles;
+  return persistent_grid(CTSEG_NUM_CU * per_cu, tiles);
 }
 
 static bool wgrad_head2(const ctseg_wgrad_desc* d) {

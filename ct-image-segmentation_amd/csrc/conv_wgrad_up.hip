@@ -246,8 +246,7 @@ static int wgrad_up_grid(const ctseg_wgrad_desc* d) {
   const int tiles = ((d->Xr + WU_TX - 1) / WU_TX) * ((d->Yr + WU_TY - 1) / WU_TY) * ((d->Zr + WU_TZ - 1) / WU_TZ) * d->N;
   int per_cu = 2;
   if (const char* e = getenv("CTSEG_WU_PER_CU")) per_cu = atoi(e);
-  const int g = 256 * per_cu;
-  return g < tiles ? g : tiles;
+  return persistent_grid(CTSEG_NUM_CU * per_cu, tiles);
 }
 
 int wgrad_up_slabs(const ctseg_wgrad_desc* d) { return wgrad_up_grid(d); }

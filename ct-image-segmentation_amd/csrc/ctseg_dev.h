@@ -7,7 +7,28 @@
 
 #include "ctseg_hip.h"
 
+#include <stdlib.h>
+
 namespace ctseg {
+
+// The one target: MI355X (gfx950) = 256 CUs in 8 XCDs, 160 KiB of LDS and 4 SIMDs x 512 VGPRs per CU.  Persistent kernels launch
+// CTSEG_NUM_CU * k workgroups (k = workgroups that fit a CU) and walk tiles with stride gridDim.x; XCD-aware orders assume 8 XCDs.
+constexpr int CTSEG_NUM_CU = 256;
+constexpr int CTSEG_NUM_XCD = 8;
+
+// Grid size of a persistent launch: min(wanted, tiles), optionally capped by the TEST-ONLY environment knob CTSEG_MAX_WG=n so that
+// small test shapes make every workgroup walk several tiles (the inter-tile paths — prefetch of tile t+1, store of tile t-1, ring-slot
+// rotation across an epilogue, statistics flush at a sample change — are otherwise reached only at 512x512x48).  Every sizing query
+// (partial-slot / slab counts) goes through the same function as its launch, so the knob must not change between recording a plan
+// and running it.  Unset in production.
+static inline int persistent_grid(int wanted, int tiles) {
+  int g = wanted < tiles ? wanted : tiles;
+  if (const char* e = getenv("CTSEG_MAX_WG")) {
+    const int cap = atoi(e);
+    if (cap >= 1 && cap < g) g = cap;
+  }
+  return g < 1 ? 1 : g;
+}
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;

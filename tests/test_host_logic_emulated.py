@@ -273,15 +273,20 @@ def test_drop_in_surface_training_step_backward_optimizer_step_equals_fit_step(e
         plain.load_state_dict(osd)
         m2 = BaseUNet3D(filters=[4, 8, 16], loss_fx=["CrossEntropy"], lr=1e-2)
         m2.load_state_dict(m.state_dict())
-        m2.unet.engine().ensure("cpu")
+        # plain torch's resume order: the optimizer state is loaded into a FRESH module, before any forward built the flat store
+        # (the moments then stayed in torch's self.state and the first native step ran on zeroed moments, step 0)
+        assert m2.unet.engine().store is None
         opt2 = m2.configure_optimizers()
         opt2.load_state_dict(osd)
+        assert m2.unet.engine().store.step == 3 and not opt2.state
         a, b = float(ref.fit_step(batch)), None
         opt2.zero_grad()
         l2 = m2.training_step(batch, 0)
         l2.backward()
         opt2.step()
-        assert float(l2) == a
+        assert float(l2.detach()) == a
+        for p, q in zip(ref.parameters(), m2.parameters()):      # the 4th update used the checkpointed moments and step count
+            assert torch.equal(p.detach(), q.detach())
         ref.load_state_dict(m.state_dict())        # rewind the reference model for the next convention
         ref.load_optimizer_state_dict(osd)
     # an upstream gradient != 1 and gradient accumulation, against the oracle (torch autograd + torch Adam)
@@ -481,3 +486,26 @@ def test_first_layer_weight_gradient_forms_its_upper_columns_on_load(emu):
     assert seen["0"][2] == 0 and seen["0"][1] == 0
     assert seen["1"][0] == seen["0"][0] - 1 and seen["1"][1] == 1, seen        # one apply pass fewer, one slope-gradient launch instead
     np.testing.assert_allclose(seen["1"][3].numpy(), seen["0"][3].numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_a_fused_loss_that_is_never_backpropagated_does_not_leak_its_gradient_into_the_next_backward(emu):
+    """the fused training_step leaves d loss / d logits in the plan and a flag saying so; if that loss is dropped
+    (skipped step, inspection under grad mode) the next forward on the plan must clear the flag, or ``model(x) + custom loss``
+    would backpropagate the PREVIOUS batch's cross-entropy gradient instead of its own upstream gradient."""
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    torch.manual_seed(11)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(1, 1, 8, 8, 8, generator=g)
+    masks = (torch.rand(1, 9, 8, 8, 8, generator=g) < 0.1).to(torch.uint8)
+    m = BaseUNet3D(filters=[4, 8, 16], loss_fx=["CrossEntropy"])
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    dropped = m.training_step((x, masks, torch.ones(1, 9)), 0)      # fused route; never backpropagated
+    assert dropped.requires_grad
+    x2 = torch.randn(1, 1, 8, 8, 8, generator=g)
+    w = torch.randn(1, 10, 8, 8, 8, generator=g)
+    (m(x2) * w).sum().backward()
+    fresh = BaseUNet3D(filters=[4, 8, 16], loss_fx=["CrossEntropy"])
+    fresh.load_state_dict(sd)
+    (fresh(x2) * w).sum().backward()
+    for p, q in zip(m.parameters(), fresh.parameters()):
+        assert torch.equal(p.grad, q.grad)
