@@ -90,6 +90,13 @@ class PackBlock(C.Structure):
 PACK_LDS_FLOATS = 12288
 
 
+class ReduceJob(C.Structure):
+    """ctseg_reduce_job: one ctseg_conv_wgrad_reduce call of a batched launch"""
+    _fields_ = [("ws", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("nslabs", C.c_int32), ("kpad_w", C.c_int32),
+                ("cn_pad", C.c_int32), ("A", C.c_int32), ("Astride", C.c_int32), ("T", C.c_int32), ("col0", C.c_int32),
+                ("nb", C.c_int32), ("block0", C.c_int32), ("lanes", C.c_int32)]
+
+
 class WgradDesc(_SizedDesc):
     _fields_ = [("struct_size", C.c_int32), ("reserved0", C.c_int32), ("in_", C.c_void_p), ("dy", C.c_void_p), ("ws", C.c_void_p), ("dtype", C.c_int32),
                 ("N", C.c_int32), ("Xi", C.c_int32), ("Yi", C.c_int32), ("Zi", C.c_int32),
@@ -121,6 +128,8 @@ _SIGS = {
     "ctseg_conv_wgrad_slabs": (C.c_int, [C.POINTER(WgradDesc)]),
     "ctseg_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
     "ctseg_conv_wgrad_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ctseg_conv_wgrad_reduce_batch_ok": (C.c_int, [_vp, _i32, _i32, _i32]),
+    "ctseg_conv_wgrad_reduce_batch": (C.c_int, [_vp, _i32, _i32, _vp]),
     "ctseg_gather_cast": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp]),
     "ctseg_pack_weights": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
     "ctseg_instnorm_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp]),

@@ -36,7 +36,10 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
-def split_points(ready_marks, sizes, n_total, fractions=(0.6, 0.92)):
+SPLIT_FRACTIONS = (0.6, 0.92)      # share of the flat gradient that is final when chunk 1 / chunk 2 of the exchange goes out
+
+
+def split_points(ready_marks, sizes, n_total, fractions=SPLIT_FRACTIONS):
     """ready_marks: [(program index, [flat offsets that became final])], sizes: {offset: numel}.
     Returns [(program index, end offset)] — after ``program index`` ops of backward the flat gradient is
     final on [0, end).  For every fraction, the earliest mark whose ready prefix covers that share of the buffer (and

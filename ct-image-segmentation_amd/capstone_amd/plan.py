@@ -435,6 +435,7 @@ class Plan:
             self.dlogits = new_act(*self.logits.dims, net.out_channels, self.dt, self.device)
             self._cur = self.bwd
             self.dx = self.root.emit_bwd(self.dlogits, need_dx=self.need_input_grad)
+            self._flush_reduces()
         self._cur = None
 
     # ---- recording ----
@@ -448,6 +449,8 @@ class Plan:
             else:
                 conv.append(a)
         self._keep.append(keep)
+        if name == "ctseg_conv_wgrad_reduce" and self._batch_reduce(conv):
+            return
         op = (name, fn, tuple(conv))
         if self._defer is not None and self._cur is self.bwd and name in self.SIDE_OPS:
             self._defer.append(op)        # head weight gradients: queued later, beside the MFMA-bound deep levels
@@ -460,11 +463,71 @@ class Plan:
         part = torch.zeros((P, rup(x.C, 8)), dtype=torch.float32, device=self.device)
         self.emit("ctseg_colsum", self.dt, x.ptr(), x.ld, rows, x.C, part.data_ptr(), P, out_ptr, keep=(x, part))
 
+    # ---- slab reduces of the weight gradients, batched ---------------------------------------------------------------------------
+    # Every weight-gradient GEMM is followed by a reduce of its fp32 slabs into the flat gradient: 18 launches of 7-15 us per step
+    # that occupied 0.44 ms of the weight-gradient stream (plus ~0.15 ms of gaps) in the overlapped trace of round 3 — each waits for
+    # the tail of its GEMM and holds back the next one — on the stream that finishes the backward last.  They read nothing but their
+    # own slabs and nothing reads their output before the gradient exchange / Adam, so they are collected and issued as ONE launch
+    # (ctseg_conv_wgrad_reduce_batch, bit-identical sums) per gradient chunk: where the ready prefix of the flat gradient crosses the
+    # split fractions of the data-parallel exchange (distributed.split_points: 60 %, 92 %) and at the end.  CTSEG_REDUCE_BATCH=0: off.
+    def _batch_reduce(self, args):
+        if (self._cur is not self.bwd or self._defer is not None or getattr(self, "_stash", None) or
+                os.environ.get("CTSEG_REDUCE_BATCH", "1") == "0"):
+            return False
+        ws, nslabs, kpad_w, cn_pad, A, AS, T, col0, nb, dw, db = args
+        if nat.lib().ctseg_conv_wgrad_reduce_batch_ok(ws, cn_pad, col0, nb) != 1:
+            return False
+        if not hasattr(self, "_pending_reduce"):
+            self._pending_reduce, self._pending_ready, self._reduce_frac = [], [], 0
+        self._pending_reduce.append(args)
+        return True
+
+    def _ready_prefix(self, extra):
+        """elements of the flat gradient final once the offsets in `extra` are (plus everything marked ready so far)"""
+        st = self.store
+        done = {o for _, offs in self.ready_marks for o in offs} | set(extra)
+        prefix = 0
+        for p in st.params:
+            if st.off(p) not in done:
+                break
+            prefix = st.off(p) + p.numel()
+        return prefix
+
+    def _flush_reduces(self, only_if_chunk=False):
+        jobs = getattr(self, "_pending_reduce", None)
+        if not jobs:
+            return
+        if only_if_chunk:
+            from .distributed import SPLIT_FRACTIONS
+            prefix, crossed = self._ready_prefix(self._pending_ready), False
+            while self._reduce_frac < len(SPLIT_FRACTIONS) and prefix >= SPLIT_FRACTIONS[self._reduce_frac] * self.store.n:
+                self._reduce_frac += 1
+                crossed = True
+            if not crossed:
+                return
+        arr = (nat.ReduceJob * len(jobs))()
+        b0 = 0
+        for J, (ws, nslabs, kpad_w, cn_pad, A, AS, T, col0, nb, dw, db) in zip(arr, jobs):
+            J.ws, J.dw, J.db = ws, dw, db
+            J.nslabs, J.kpad_w, J.cn_pad, J.A, J.Astride, J.T, J.col0, J.nb = nslabs, kpad_w, cn_pad, A, AS, T, col0, nb
+            J.lanes = 8 if nslabs >= 64 else 32
+            J.block0 = b0
+            b0 += -(-((T * AS + 1) * ((nb + 3) // 4)) // J.lanes)
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.device)
+        ready, self._pending_reduce, self._pending_ready = self._pending_ready, [], []
+        self.emit("ctseg_conv_wgrad_reduce_batch", table.data_ptr(), len(jobs), b0, keep=(table,))
+        if ready:
+            self.ready_marks.append((len(self.bwd), ready))
+
     def grads_ready(self, params):
         if self._cur is self.bwd:
             offs = [self.store.off(p) for p in params if p is not None]
             if self._defer is not None:
                 self._defer.append(("ready", offs))
+            elif getattr(self, "_pending_reduce", None):
+                # (some of) these gradients come out of reduces that are still collected: final when the batch is issued
+                self._pending_ready.extend(offs)
+                self._flush_reduces(only_if_chunk=True)
             else:
                 self.ready_marks.append((len(self.bwd), offs))
 
@@ -565,7 +628,8 @@ class Plan:
     # weight-gradient work (split-K GEMM + slab reduce, transposed-conv bias sums) depends only on tensors that are final when
     # it is recorded and feeds nothing but the flat gradient buffer: it runs on a second HIP stream, so an LDS-port-bound
     # weight-gradient kernel shares the GPU with the HBM-bound norm passes / input-gradient convs of the next layers
-    SIDE_OPS = ("ctseg_conv_wgrad", "ctseg_conv_wgrad_reduce", "ctseg_colsum", "ctseg_instnorm_prelu_dalpha")
+    SIDE_OPS = ("ctseg_conv_wgrad", "ctseg_conv_wgrad_reduce", "ctseg_conv_wgrad_reduce_batch", "ctseg_colsum",
+                "ctseg_instnorm_prelu_dalpha")
 
     def side_stream(self):
         """the second HIP stream of this plan (None on CPU / when CTSEG_SIDE_STREAM=0)"""

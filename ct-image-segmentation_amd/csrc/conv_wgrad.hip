@@ -457,6 +457,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void wgra
   }
 }
 
+// wgrad_reduce4_kernel for a table of passes: block -> job by a scan of the (few) block0 entries, then exactly the arithmetic of
+// wgrad_reduce4_kernel<LW, 256 / LW> with LW = job.lanes (8 or 32): the same strided sub-sums, the same combine order.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void wgrad_reduce_batch_kernel(const ctseg_reduce_job* __restrict__ jobs, int n_jobs) {
+  __shared__ f32x4 s_part[256];
+  int j = 0;
+  while (j + 1 < n_jobs && (int)blockIdx.x >= jobs[j + 1].block0) ++j;       // (uniform: scalar loads)
+  const ctseg_reduce_job J = jobs[j];
+  const int LW = J.lanes, NSUB = 256 / LW;
+  const int nb4 = (J.nb + 3) >> 2, total4 = (J.T * J.Astride + 1) * nb4;
+  const int64_t slab = (int64_t)J.kpad_w * J.cn_pad;
+  const int el = threadIdx.x % LW, sub = threadIdx.x / LW;
+  const int i4 = ((int)blockIdx.x - J.block0) * LW + el;
+  const int k = i4 / nb4, b0 = (i4 - k * nb4) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < total4) {
+    const float* p = J.ws + (int64_t)k * J.cn_pad + J.col0 + b0;
+#pragma unroll 2
+    for (int q = sub; q < J.nslabs; q += NSUB) s += *reinterpret_cast<const f32x4*>(p + q * slab);
+  }
+  s_part[sub * LW + el] = s;
+  __syncthreads();
+  if (sub == 0 && i4 < total4) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int q = 0; q < NSUB; ++q) t += s_part[q * LW + el];
+    if (k == J.T * J.Astride) {
+      if (J.db != nullptr)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (b0 + e < J.nb) J.db[b0 + e] = t[e];
+    } else {
+      const int tt = k / J.Astride, a = k - tt * J.Astride;
+      if (a < J.A)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (b0 + e < J.nb) J.dw[((int64_t)(b0 + e) * J.A + a) * J.T + tt] = t[e];
+    }
+  }
+}
+
 bool wgrad_up_eligible(const ctseg_wgrad_desc* d);
 int wgrad_up_slabs(const ctseg_wgrad_desc* d);
 void launch_wgrad_up(const ctseg_wgrad_desc* d, hipStream_t st);
@@ -605,5 +645,17 @@ extern "C" int ctseg_conv_wgrad_reduce(const float* ws, int32_t nslabs, int32_t 
     hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws, nslabs, kpad_w, cn_pad, A, AS, T,
                        col0, nb, dw, db);
   CTSEG_LAUNCH_CHECK("wgrad_reduce");
+  return 0;
+}
+
+extern "C" int ctseg_conv_wgrad_reduce_batch_ok(const float* ws, int32_t cn_pad, int32_t col0, int32_t nb) {
+  return ((col0 & 3) == 0 && (cn_pad & 3) == 0 && col0 + ((nb + 3) & ~3) <= cn_pad && ((uintptr_t)ws & 15) == 0 &&
+          getenv("CTSEG_WGRAD_REDUCE_SCALAR") == nullptr) ? 1 : 0;
+}
+
+extern "C" int ctseg_conv_wgrad_reduce_batch(const ctseg_reduce_job* jobs, int32_t n_jobs, int32_t total_blocks, void* stream) {
+  CTSEG_REQUIRE(jobs && n_jobs >= 1 && total_blocks >= 1, "wgrad_reduce_batch: bad arguments");
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs);
+  CTSEG_LAUNCH_CHECK("wgrad_reduce_batch");
   return 0;
 }

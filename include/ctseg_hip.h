@@ -186,6 +186,23 @@ int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream);
  * db[b] = sum_s ws[s][T*Astride][col0+b] (db may be NULL).  Astride = the pass's (padded) Cg. */
 int ctseg_conv_wgrad_reduce(const float* ws, int32_t nslabs, int32_t kpad_w, int32_t cn_pad, int32_t A, int32_t Astride,
                             int32_t T, int32_t col0, int32_t nb, float* dw, float* db, void* stream);
+/* The same reduction for SEVERAL weight-gradient passes in ONE launch: `jobs` is a device array of the arguments above (one entry
+ * per ctseg_conv_wgrad_reduce call it replaces), results bit-identical to the per-pass calls (same partition of the slabs, same
+ * fixed-order combine).  Replaces the 18 slab reduces of a training step (autograd's per-parameter gradient accumulation,
+ * capstone/volumetric/base_trainer.py:80-82 -> loss.backward()) by one launch per gradient chunk: on the weight-gradient stream
+ * every small launch between two GEMMs waits for the tail of the one before it.  block0 / lanes are filled by the caller:
+ * lanes = 8 when nslabs >= 64 else 32 (float4 lanes along a slab row); blocks = ceil((T * Astride + 1) * ceil(nb / 4) / lanes);
+ * block0 = running sum of the blocks of the jobs before it; total_blocks = the sum over all jobs.  Every job needs col0 % 4 == 0,
+ * cn_pad % 4 == 0, col0 + roundup(nb, 4) <= cn_pad and a 16-byte aligned ws (ctseg_conv_wgrad_reduce_batch_ok). */
+typedef struct ctseg_reduce_job {
+  const float* ws;
+  float* dw;
+  float* db;                     /* may be NULL */
+  int32_t nslabs, kpad_w, cn_pad, A, Astride, T, col0, nb;
+  int32_t block0, lanes;
+} ctseg_reduce_job;
+int ctseg_conv_wgrad_reduce_batch_ok(const float* ws, int32_t cn_pad, int32_t col0, int32_t nb);
+int ctseg_conv_wgrad_reduce_batch(const ctseg_reduce_job* jobs, int32_t n_jobs, int32_t total_blocks, void* stream);
 
 /* dst[i] = (dtype) src[idx[i]], i < n.  With a host-built index this turns the flat fp32 parameter buffer
  * (torch Conv/ConvTranspose weight layouts) into every K-contiguous packed operand of the passes above in

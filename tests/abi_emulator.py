@@ -150,6 +150,22 @@ class Emulator:
         if db:
             mem(db, nb)[:] = w[T * AS, col0:col0 + nb]
 
+    def conv_wgrad_reduce_batch_ok(self, ws, cn_pad, col0, nb):
+        return int(col0 % 4 == 0 and cn_pad % 4 == 0 and col0 + (nb + 3) // 4 * 4 <= cn_pad and ws % 16 == 0)
+
+    def conv_wgrad_reduce_batch(self, jobs, n_jobs, total_blocks):
+        """ctseg_conv_wgrad_reduce_batch: the per-pass reduce, job by job (the block bookkeeping is checked against the contract)"""
+        import sys
+        nat = sys.modules["capstone_amd._native"]
+        arr = (nat.ReduceJob * n_jobs).from_address(jobs)
+        b0 = 0
+        for j in range(n_jobs):
+            J = arr[j]
+            assert J.lanes == (8 if J.nslabs >= 64 else 32) and J.block0 == b0, (j, J.lanes, J.block0, b0)
+            b0 += -(-((J.T * J.Astride + 1) * ((J.nb + 3) // 4)) // J.lanes)
+            self.conv_wgrad_reduce(J.ws, J.nslabs, J.kpad_w, J.cn_pad, J.A, J.Astride, J.T, J.col0, J.nb, J.dw, J.db)
+        assert b0 == total_blocks, (b0, total_blocks)
+
     def pack_weights(self, src, blocks, n_blocks, rows, n_rows, dst, dtype):
         """ctseg_pack_weights: the structured re-layout, row by row as the kernel does it"""
         import sys

@@ -157,3 +157,41 @@ def test_dice_focal_drop_in_step_with_capped_grids(monkeypatch):
     assert abs(grads["3"][0] - grads[None][0]) < 2e-3 * abs(grads[None][0])
     a, b = grads["3"][1], grads[None][1]
     assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.9999
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Round 4: the slab reduces of a backward pass as ONE launch per gradient chunk (ctseg_conv_wgrad_reduce_batch)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,filters,precision", [((2, 32, 48, 16), [16, 32, 64], "bf16"), ((2, 64, 64, 32), [32, 64, 128, 256], "bf16"),
+                                                     ((1, 24, 40, 16), [8, 16, 32], "fp32")])
+def test_batched_slab_reduce_is_bit_identical_to_the_per_pass_reduces(monkeypatch, shape, filters, precision):
+    """same partition of the slabs, same fixed-order combine -> the SAME flat gradient bit for bit, from 3 launches instead of one
+    per weight-gradient pass; the readiness marks still give the data-parallel exchange a chunk to send mid-backward"""
+    from capstone_amd import distributed as cdist
+    from capstone_amd.volumetric.base_trainer import BaseUNet3D
+    B, H, W, D = shape
+    g = torch.Generator().manual_seed(61)
+    images = torch.randn(B, 1, H, W, D, generator=g).to(DEV)
+    masks = (torch.rand(B, 9, H, W, D, generator=g) < 0.08).to(torch.uint8).to(DEV)
+    batch = (images, masks, torch.ones(B, 9, dtype=torch.float64).to(DEV))
+    out = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("CTSEG_REDUCE_BATCH", on)
+        torch.manual_seed(19)
+        m = BaseUNet3D(filters=list(filters), loss_fx=["CrossEntropy"], precision=precision).to(DEV)
+        loss = float(m.fit_step(batch, keep_logits=False))
+        eng = m.unet.engine()
+        plan = eng.last_plan
+        names = [nm for nm, *_ in plan.bwd]
+        torch.cuda.synchronize()
+        st = eng.store
+        sizes = {st.off(p): p.numel() for p in st.params}
+        out[on] = (loss, st.flat_g.clone(), names.count("ctseg_conv_wgrad_reduce"), names.count("ctseg_conv_wgrad_reduce_batch"),
+                   cdist.split_points(plan.ready_marks, sizes, st.n), st.flat_p.clone())
+    a, b = out["0"], out["1"]
+    assert a[3] == 0 and a[2] >= 6
+    assert b[2] == 0 and 1 <= b[3] <= 3, b[2:4]
+    assert a[0] == b[0]
+    assert torch.equal(a[1], b[1]), float((a[1] - b[1]).abs().max())
+    assert torch.equal(a[5], b[5])                       # ... and so is the Adam update
+    assert len(b[4]) >= 1 and all(0 < end < a[1].numel() for _, end in b[4])
