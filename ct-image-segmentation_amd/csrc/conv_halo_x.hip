@@ -21,7 +21,7 @@
 #include "conv_common.h"
 
 #ifndef X_ABL
-#define X_ABL 0      // timing-only ablation builds (tools/ablate_halo_x.sh): 1 = no MFMAs, 2 = no stores, 4 = no DMA, 128 = no 8-byte staging stores (12-wide rows); results are garbage
+#define X_ABL 0      // timing-only ablation builds (tools/ablate_halo_x.sh): 1 = no MFMAs, 2 = no stores, 4 = no DMA, 128 = no 8-byte staging stores (12-wide rows), 256 = no tile barrier, 1024 = no operand reads, 2048 = no logits exchange (fused head; tools/ablate_head_ce_r4.sh -> profiles/r04_fused_head_ablation.txt); results are garbage
 #endif
 
 namespace ctseg {
@@ -105,6 +105,9 @@ struct XCe {
 // load consumed in the tile it is issued in puts an HBM round trip on every tile), and accumulates the three sums per lane; they
 // are combined per workgroup at every sample change, as the forward statistics are.
 template <typename H, int VB, int NT, int NS, bool FLIP, bool STATS, int ADD, bool OF32, bool R12, bool CE = false, bool BST = false>
+// (Round 4: a third workgroup per CU for the 32-byte-voxel DMA-staged variants — __launch_bounds__(256, 3): 168 registers, 12-64 B of
+// scratch — bought nothing: logits conv on 16-wide rows 0.592 ms at 2 / CU, 0.616 at 3 / CU with the 2-per-CU build, 0.649 / 0.638 with
+// the 168-register build.  Occupancy is not what these passes wait for.)
 __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) void conv_halo_x_kernel(const ConvKArgs P, const XGeom G, int total_tiles, const XCe E) {
   static_assert(!BST || (!STATS && !OF32 && !CE && ADD != 2), "backward statistics: 16-bit gradient passes without a global-memory addend");
   static_assert(!R12 || (VB == 32 && NS == 1), "12-wide rows: 16 gathered channels, one wave group");
@@ -666,7 +669,10 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
     u32x4 F[2][X_HX], Wb[2][WL ? NT : 1][WL ? 3 : 1];
     auto load_group = [&](int t, u32x4 (&f)[X_HX], u32x4 (&w)[WL ? NT : 1][WL ? 3 : 1]) {
 #pragma unroll
-      for (int h = 0; h < X_HX; ++h) f[h] = *reinterpret_cast<const u32x4*>(frag_base(t) + h * X_XSTRIDE);
+      for (int h = 0; h < X_HX; ++h) {
+        if constexpr ((X_ABL & 1024) != 0) f[h] = u32x4{(uint32_t)tid, (uint32_t)h, (uint32_t)t, 0u};     // (timing only: no operand reads)
+        else f[h] = *reinterpret_cast<const u32x4*>(frag_base(t) + h * X_XSTRIDE);
+      }
       if constexpr (WL) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -793,6 +799,10 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
     // (two rounds of two planes: 1.5 KB of scratch per wave, so that three workgroups fit a CU; lanes q4 = 2r, 2r+1 read in round r)
     char* sc = sT + wave * (2 * 16 * 48);
     float x[12];
+    if constexpr ((X_ABL & 2048) != 0) {      // (timing only: no exchange through LDS)
+#pragma unroll
+      for (int q = 0; q < 12; ++q) x[q] = acc[0][q & 3][q >> 2] + bias[0][q & 3];
+    } else
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
 #pragma unroll
@@ -965,7 +975,7 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
     int lab_cur = ce_label(ocur), lab_next = 0;
     for (;; t += stride, buf ^= 1) {
       const bool more = t + stride < last;
-      if constexpr (R12) __syncthreads();
+      if constexpr (R12) { if (!(X_ABL & 256)) __syncthreads(); }
       else { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
       if (more) {
         onext = tile_origin(t + stride);
