@@ -780,11 +780,17 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
   };
   // the label of this lane's voxel of a tile (x plane q4, patch voxel r16): requested ONE TILE AHEAD — loaded inside the epilogue it
   // put a full HBM round trip on every tile of the workgroup (0.9 ms per launch instead of ~0.5)
+  // (Round 4: the voxel index of a lane = a per-lane constant + a scalar tile base inside a per-sample buffer range — the 64-bit
+  // per-lane multiply chain of ((n Xo + x) Yo + y) Zo + z was eight quarter-rate instructions per tile and wave, here for the label
+  // and again for the gradient store.  A sample's voxel count x row bytes is < 2^31: conv_halo_x_eligible checks the output tensor.)
+  const int ce_vox = CE ? (q4 * P.Yo + 2 * yp + pdy) * P.Zo + pz : 0;       // this lane's voxel inside a tile at the origin
+  const int ce_svox = P.Xo * P.Yo * P.Zo;
   auto ce_label = [&](const Org& o) -> int {
     const int xg = o.x0 + q4, yg = o.y0 + 2 * yp + pdy, zg = o.z0 + pz;
     const bool valid = xg < P.Xr && yg < P.Yr && zg < P.Zr;
-    const int64_t vox = (((int64_t)o.n * P.Xo + xg) * P.Yo + yg) * P.Zo + zg;
-    return valid ? (int)E.labels[vox] : 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(E.labels) + (int64_t)o.n * ce_svox, 0, ce_svox, 0x00020000);
+    const int tbase = (o.x0 * P.Yo + o.y0) * P.Zo + o.z0;
+    return (int)__builtin_amdgcn_raw_buffer_load_b8(rs, valid ? ce_vox : (int)0x80000000, tbase, 0);     // out of range: 0
   };
   auto ce_epilogue = [&](const Org& o, f32x4 (&acc)[NT][X_TX], u32x2 (&cadd)[NT][X_TX], int t) {
     if (o.n != ce_n) {
@@ -828,8 +834,8 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
     const int C = E.C;
     const int xg = o.x0 + q4, yg = o.y0 + 2 * yp + pdy, zg = o.z0 + pz;
     const bool valid = xg < P.Xr && yg < P.Yr && zg < P.Zr;
-    const int64_t vox = (((int64_t)o.n * P.Xo + xg) * P.Yo + yg) * P.Zo + zg;
-    if constexpr ((X_ABL & 8) != 0) {        // timing-only: no loss arithmetic, one store
+    if constexpr ((X_ABL & 8) != 0) {
+      const int64_t vox = (((int64_t)o.n * P.Xo + xg) * P.Yo + yg) * P.Zo + zg;        // timing-only: no loss arithmetic, one store
       if (valid) *reinterpret_cast<u32x2*>(E.dlogits + vox * E.g_ld * 2) = u32x2{__float_as_uint(x[0] + x[5] + x[9]), (uint32_t)t};
       return;
     }
@@ -920,11 +926,23 @@ __global__ __launch_bounds__(256 * NS, (BST && VB == 32 && NS == 1) ? 2 : 1) voi
       const f32x2 g2 = (ep[k] * f32x2{rs, rs} - oh[k]) * f32x2{ce_scale, ce_scale};     // (columns >= C: e = 0, oh = 0)
       d[2 * k] = g2[0]; d[2 * k + 1] = g2[1];
     }
-    if ((X_ABL & 16) ? (valid && d[0] + d[5] == 123.f) : valid) {
-      char* gp = E.dlogits + vox * E.g_ld * 2;
-#pragma unroll
-      for (int u = 0; u < 3; ++u)
-        *reinterpret_cast<u32x2*>(gp + u * 8) = u32x2{pack2<H>(d[4 * u], d[4 * u + 1]), pack2<H>(d[4 * u + 2], d[4 * u + 3])};
+    {
+      const bool st_ok = (X_ABL & 16) ? (valid && d[0] + d[5] == 123.f) : valid;
+      const int row = E.g_ld * 2;
+      const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(E.dlogits + (int64_t)o.n * ce_svox * row, 0, ce_svox * row, 0x00020000);
+      const int gbase = ((o.x0 * P.Yo + o.y0) * P.Zo + o.z0) * row;
+      const int gvo = st_ok ? ce_vox * row : (int)0x80000000;
+      const u32x4 lo = {pack2<H>(d[0], d[1]), pack2<H>(d[2], d[3]), pack2<H>(d[4], d[5]), pack2<H>(d[6], d[7])};
+      const u32x2 hi = {pack2<H>(d[8], d[9]), pack2<H>(d[10], d[11])};
+      if (E.g_ld % 8 == 0) {       // 16-wide rows: 16-byte aligned
+        __builtin_amdgcn_raw_buffer_store_b128(lo, grs, gvo, gbase, 0);
+        asm volatile("s_nop 1" ::"v"(lo));        // (>64-bit store data with an SGPR offset: see the fp32 logits store above)
+        __builtin_amdgcn_raw_buffer_store_b64(hi, grs, gvo + 16, gbase, 0);
+      } else {                     // 12-wide rows (24 bytes, 8-byte aligned): three 8-byte stores
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{lo[0], lo[1]}, grs, gvo, gbase, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{lo[2], lo[3]}, grs, gvo + 8, gbase, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(hi, grs, gvo + 16, gbase, 0);
+      }
     }
   };
 

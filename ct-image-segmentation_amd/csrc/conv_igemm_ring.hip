@@ -154,6 +154,8 @@ __device__ __forceinline__ void ring_main(const ConvKArgs& P, const ctseg_conv_c
     __builtin_amdgcn_s_barrier();                         // ... and everyone else's
     __builtin_amdgcn_sched_barrier(0);
     const int sl1 = sl + 1 == D ? 0 : sl + 1, slp = sl == 0 ? D - 1 : sl - 1;
+    // (Round 4, same box, 256 -> 256: static s_setprio 1 for waves 4-7 0.1442 -> 0.1450 ms; waves 4-7 reading their fragments BEHIND
+    // their multiplies instead of ahead of them 0.1465; both 0.1507 — the two waves of a SIMD are not helped by being told apart.)
     if constexpr (FR) frags(sl1, x1, w1);
     if constexpr (DMA) dma(slp);
     mmas(x0, w0);
