@@ -492,7 +492,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (!nrm) {
 #pragma unroll
       for (int j = 0; j < JX; ++j)
-        if (JX * 512 == XN || tid + j * 512 < XN) *reinterpret_cast<u32x2*>(smem + xl[j]) = rx[j];
+        if ((JX * 512 == XN || tid + j * 512 < XN) && (!(WH_ABL & 8) || rx[j][0] == 0x12345u)) *reinterpret_cast<u32x2*>(smem + xl[j]) = rx[j];
     } else {
       int n;
       const uint32_t xm = xmask(t, n);
@@ -529,6 +529,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     ones = s16x8{o, o, o, o, o, o, o, o};
   }
   auto tr_frag = [&](const char* p0, int hi_off) -> bf16x8 {
+    if constexpr ((WH_ABL & 2) != 0) { const short v0 = (short)(uintptr_t)p0; return __builtin_bit_cast(bf16x8, s16x8{v0, v0, v0, v0, v0, v0, v0, v0}); }   // (timing only)
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + hi_off));
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -552,7 +553,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int dxi = 0; dxi < 3; ++dxi)
 #pragma unroll
-          for (int p = 0; p < 4; ++p) acc[ci][dxi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[p + dxi], df[p], acc[ci][dxi], 0, 0, 0);
+          for (int p = 0; p < 4; ++p) {
+            if constexpr ((WH_ABL & 1) != 0) { acc[ci][dxi][0] += __builtin_bit_cast(f32x4, xf[p + dxi])[0] * __builtin_bit_cast(f32x4, df[p])[1]; continue; }   // (timing only)
+            acc[ci][dxi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[p + dxi], df[p], acc[ci][dxi], 0, 0, 0);
+          }
       }
     }
     if (cg == 3) {       // pseudo tap 27: row 0 accumulates sum(dy) (bias gradient)
