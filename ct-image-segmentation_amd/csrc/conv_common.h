@@ -337,6 +337,7 @@ int conv_down_halo_bst_slots(const ConvKArgs& a);   // 0: this pass cannot take 
 void launch_conv_down_halo(ConvKArgs& a, hipStream_t st);
 bool conv_down_r_eligible(const ConvKArgs& a, int dtype, int nclass);
 int conv_down_r_slots(const ConvKArgs& a);
+int conv_down_r_bst_slots(const ConvKArgs& a);   // 0: this pass cannot take ConvKArgs::bst
 void launch_conv_down_r(ConvKArgs& a, hipStream_t st);
 // conv_igemm_ring.hip: the 192 x 256 bf16 tile with a five-deep ring of 32-wide K stages (a.tiles already set for 192 rows)
 bool conv_ring_eligible(const ConvKArgs& a, int dtype, int nclass);

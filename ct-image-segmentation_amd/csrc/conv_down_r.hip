@@ -56,8 +56,15 @@ struct DownRGeom {
   int a_fast;                // tile order: the 1-deep axis fastest
 };
 
-template <typename H, bool STATS>
+// BST (round 4): backward InstanceNorm statistics of the written gradient (ConvKArgs::bst) for the waves whose 16 columns are channels
+// of the norm — here the sub-block half of the level-1 concat gradient.  A wave owns its columns, so the three sums need neither LDS
+// nor a barrier: a lane keeps them for its 4 channels over the workgroup's tiles and the 16 voxel lanes are combined by a butterfly at
+// every sample change, one partial row per workgroup and sample (the layout ctseg_instnorm_prelu_bwd_finalize sums).  The y values of a
+// tile are requested BEFORE the next tile's DMA pieces (the counted wait at the loop head covers exactly the stores behind the DMA) and
+// consumed behind its 108 multiplies: a tile lasts ~4 us here, longer than the round trip.
+template <typename H, bool STATS, bool BST = false>
 __global__ __launch_bounds__(DR_NTHR) void conv_down_r_kernel(const ConvKArgs P, const DownRGeom G, int total_tiles) {
+  static_assert(!(STATS && BST), "forward statistics or backward statistics");
   __shared__ __attribute__((aligned(16))) char smem[2 * DR_HALO + 64 * 4];
   int* const sTab = reinterpret_cast<int*>(smem + 2 * DR_HALO);   // per tap: [0,32) halo byte offset, [32,64) XOR flags
   const int tid = threadIdx.x, lane = tid & 63;
@@ -167,6 +174,41 @@ __global__ __launch_bounds__(DR_NTHR) void conv_down_r_kernel(const ConvKArgs P,
     }
   };
 
+  // ---- BST state ----------------------------------------------------------------------------------------------------------------
+  const bool ywave = BST && col0 >= P.bst.col0 && col0 + 16 <= P.bst.col0 + P.bst.C;      // wave-uniform
+  const int ych = BST ? col0 - P.bst.col0 + 4 * q4 : 0;                                    // the lane's first channel of the norm
+  const float bal = BST ? P.bst.alpha[0] : 1.f;
+  float brs[4] = {0.f, 0.f, 0.f, 0.f}, bnm[4] = {0.f, 0.f, 0.f, 0.f};                      // rstd, -mean * rstd of the lane's channels
+  float b1[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f}, b3 = 0.f;
+  int bst_n = -1;
+  const int y_sample_bytes = BST ? (int)((int64_t)P.Xo * P.Yo * P.Zo * P.bst.y_ld * 2) : 0;   // < 2^31 (host-checked)
+  auto bst_consts = [&](int n) {
+    if (ywave) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float mean = P.bst.mr[((int64_t)n * P.bst.C + ych + e) * 2], rstd = P.bst.mr[((int64_t)n * P.bst.C + ych + e) * 2 + 1];
+        brs[e] = rstd;
+        bnm[e] = -mean * rstd;
+      }
+    }
+  };
+  auto flush_bst = [&](int n) {
+    if (ywave) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = b1[e], b = b2[e], c = e == 0 ? b3 : 0.f;        // (one PReLU slope: only the total of the third sum matters)
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
+        if (r16 == 0) {
+          float* row = P.bst.part + ((int64_t)n * P.bst.P + blockIdx.x) * 3 * P.bst.ld + ych + e;
+          row[0] = a; row[P.bst.ld] = b; row[2 * P.bst.ld] = c;
+        }
+        b1[e] = 0.f; b2[e] = 0.f;
+      }
+      b3 = 0.f;
+    }
+  };
+
   const int GX = gridDim.x;
   int first, stride, last;
   if ((GX & 7) == 0) {
@@ -187,9 +229,25 @@ __global__ __launch_bounds__(DR_NTHR) void conv_down_r_kernel(const ConvKArgs P,
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();        // ... for every wave; and every wave is done reading the other buffer
     asm volatile("" ::: "memory");
-    if (t + stride < last) dma(t + stride, buf ^ 1);
     int n, a0, b0, c0;
     tile_origin(t, n, a0, b0, c0);
+    u32x2 yv[4] = {u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}};
+    if constexpr (BST) {
+      if (n != bst_n) {
+        if (bst_n >= 0) flush_bst(bst_n);
+        bst_n = n;
+        bst_consts(n);
+      }
+      // y of this tile's voxels, ahead of the next tile's DMA pieces (always issued: the counted wait at the loop head)
+      const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P.bst.y) + (int64_t)n * y_sample_bytes, 0, y_sample_bytes, 0x00020000);
+      const int ysoff = (a0 * G.oa + b0 * G.ob + c0 * G.oc) * P.bst.y_ld * 2;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const bool rv = ywave && (b0 + 2 * rt + pb < G.db) && (c0 + pc < G.dc);
+        yv[rt] = __builtin_amdgcn_raw_buffer_load_b64(yrs, rv ? (ooff[rt] * P.bst.y_ld + ych) * 2 : (int)0x80000000, ysoff, 0);
+      }
+    }
+    if (t + stride < last) dma(t + stride, buf ^ 1);
     if (STATS && n != stat_n) {
       if (stat_n >= 0) flush_stats(stat_n);
       stat_n = n;
@@ -227,12 +285,27 @@ __global__ __launch_bounds__(DR_NTHR) void conv_down_r_kernel(const ConvKArgs P,
         v[e] = acc[rt][e] + bias[e];
         if (STATS && rv) { wsum[e] += v[e]; wsq[e] += v[e] * v[e]; }
       }
-      __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])}, ors,
-                                            (rv && (!(DR_ABL & 8) || v[0] + v[1] == 1.2345f)) ? (ooff[rt] * old_ + ocol + 4 * q4) * 2 : (int)0x80000000, soff, 0);
+      const u32x2 o2 = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
+      __builtin_amdgcn_raw_buffer_store_b64(o2, ors, (rv && (!(DR_ABL & 8) || v[0] + v[1] == 1.2345f)) ? (ooff[rt] * old_ + ocol + 4 * q4) * 2 : (int)0x80000000, soff, 0);
+      if constexpr (BST) {
+        if (ywave && rv) {       // the sums are over the STORED gradient (rounded to the storage type), as the reduce pass reads it
+          const float g4[4] = {h2f<H>(o2[0] & 0xffffu), h2f<H>(o2[0] >> 16), h2f<H>(o2[1] & 0xffffu), h2f<H>(o2[1] >> 16)};
+          const float y4[4] = {h2f<H>(yv[rt][0] & 0xffffu), h2f<H>(yv[rt][0] >> 16), h2f<H>(yv[rt][1] & 0xffffu), h2f<H>(yv[rt][1] >> 16)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = fmaf(y4[e], brs[e], bnm[e]);
+            const float dxh = g4[e] * (xh > 0.f ? 1.f : bal);
+            b1[e] += dxh;
+            b2[e] = fmaf(dxh, xh, b2[e]);
+            b3 = fmaf(g4[e], fminf(xh, 0.f), b3);
+          }
+        }
+      }
     }
     stores_in_flight = true;
   }
   if (STATS && stat_n >= 0) flush_stats(stat_n);
+  if constexpr (BST) { if (bst_n >= 0) flush_bst(bst_n); }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -289,6 +362,16 @@ int conv_down_r_slots(const ConvKArgs& a) {
   return down_r_grid(a, g);
 }
 
+// ConvKArgs::bst on this pass (bf16, no forward statistics, no bias): whole 16-column blocks of the written columns, y in 8-byte pieces
+int conv_down_r_bst_slots(const ConvKArgs& a) {
+  { const char* e = getenv("CTSEG_BST_DOWN_R"); if (e != nullptr && e[0] == '0') return 0; }   // (A/B switch)
+  if (a.dtype != CTSEG_BF16 || a.stats != nullptr || a.bias != nullptr) return 0;
+  if (a.bst.C <= 0 || (a.bst.C % 16) != 0 || (a.bst.col0 % 16) != 0 || a.bst.col0 + a.bst.C > 128) return 0;
+  if ((a.bst.y_ld % 4) != 0 || a.bst.y_ld < a.bst.C || ((uintptr_t)a.bst.y % 8) != 0) return 0;
+  if ((int64_t)a.Xo * a.Yo * a.Zo * a.bst.y_ld * 2 >= (1ll << 31)) return 0;
+  return conv_down_r_slots(a);
+}
+
 void launch_conv_down_r(ConvKArgs& a, hipStream_t st) {
   DownRGeom g;
   down_r_geom(a, g);
@@ -296,6 +379,10 @@ void launch_conv_down_r(ConvKArgs& a, hipStream_t st) {
   const int total = g.tiles * a.N;
   const dim3 grid((unsigned)down_r_grid(a, g)), blk(DR_NTHR);
   const bool stats = a.stats != nullptr;
+  if (a.bst.part != nullptr) {        // (bf16, no forward statistics: conv_down_r_bst_slots)
+    hipLaunchKernelGGL((conv_down_r_kernel<BF16, false, true>), grid, blk, 0, st, a, g, total);
+    return;
+  }
   if (a.dtype == CTSEG_F16) {
     if (stats) hipLaunchKernelGGL((conv_down_r_kernel<F16, true>), grid, blk, 0, st, a, g, total);
     else hipLaunchKernelGGL((conv_down_r_kernel<F16, false>), grid, blk, 0, st, a, g, total);

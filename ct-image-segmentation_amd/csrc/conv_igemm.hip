@@ -308,7 +308,7 @@ static int bst_slots_for(const ConvKArgs& a, int dtype, int nclass, bool smallc)
   if (conv_up_eligible(a, dtype, nclass) || conv_stem_eligible(a, dtype, nclass)) return 0;
   if (conv_halo_sw_eligible(a, dtype, nclass)) return conv_halo_sw_bst_slots(a, nclass);
   if (conv_down_halo_eligible(a, dtype, nclass)) return conv_down_halo_bst_slots(a);
-  if (conv_down_r_eligible(a, dtype, nclass)) return 0;
+  if (conv_down_r_eligible(a, dtype, nclass)) return conv_down_r_bst_slots(a);
   if (conv_up8_eligible(a, dtype, nclass)) return 0;
   { const char* e = getenv("CTSEG_BST_GENERIC"); if (e != nullptr && e[0] == '0') return 0; }   // (A/B switch)
   // generic / ring kernels (conv_epilogue): one partial row per (class, tile); whole 16-byte chunks of y beside those of the output
