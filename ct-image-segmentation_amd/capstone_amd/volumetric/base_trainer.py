@@ -145,7 +145,10 @@ class _DataParallelSurface:
         kept = self.__dict__.get("_dice_counts", {}).get(prefix)
         if not kept:
             return None
-        cnt = cdist.gather_dice_counts(torch.stack(kept), group)          # (steps, world * B, 3, C)
+        if len({tuple(k.shape) for k in kept}) == 1:
+            cnt = list(cdist.gather_dice_counts(torch.stack(kept), group))  # ONE collective: (steps, world * B, 3, C)
+        else:                                                               # a short last batch: one small collective per step
+            cnt = [cdist.gather_dice_counts(k, group) for k in kept]
         if reset:
             self._dice_counts[prefix] = []
         eng = segloss.SegLossEngine.__new__(segloss.SegLossEngine)
