@@ -126,6 +126,7 @@ _SIGS = {
     "ctseg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "ctseg_wgrad_tile_cols": (C.c_int, [_i32]),
     "ctseg_conv_wgrad_slabs": (C.c_int, [C.POINTER(WgradDesc)]),
+    "ctseg_conv_wgrad_wgs_per_slab": (C.c_int, [C.POINTER(WgradDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ctseg_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
     "ctseg_conv_wgrad_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ctseg_conv_wgrad_reduce_batch_ok": (C.c_int, [_vp, _i32, _i32, _i32]),

@@ -470,6 +470,40 @@ class GemmLayer:
         d.dyn_g_ld, d.dyn_y_ld = rup(y.C, nat.epc(self.plan.dt)), y.ld
         return nat.query("ctseg_wgrad_dy_norm_ok", d) == 1
 
+    def _wgrad_splits(self, d, N, rows, on_load):
+        """row ranges per sample of a split-K weight-gradient pass.  The library says how many workgroups one slab takes and how
+        many a CU holds (ctseg_conv_wgrad_wgs_per_slab); ``on_load``: the descriptor will carry dyn_* / in_norm fields (generic
+        kernel whatever the query says for the plain descriptor)"""
+        plan, lib = self.plan, nat.lib()
+        per_cu, stage_bytes = C.c_int32(0), C.c_int32(0)
+        wps = lib.ctseg_conv_wgrad_wgs_per_slab(C.byref(d), C.byref(per_cu), C.byref(stage_bytes))
+        m = 8 // math.gcd(N, 8)       # slabs (N * splits) in multiples of 8: all tiles of a slab then run on one XCD (one L2 fetch of its rows)
+        if wps > 0 and per_cu.value == 1 and not on_load and "CTSEG_WGRAD_TARGET_WGS" not in os.environ:
+            # one 512-thread workgroup per CU.  Cost of a split count s (microseconds, constants measured on the MI355X, DESIGN.md 3.2k):
+            #   rounds of 256 workgroups x stages per workgroup x time of a stage (its staging bytes at ~60 GB/s per CU, never below 0.25 us)
+            #   + a fixed ~6 us per round (ring fill, accumulator store)
+            #   + the fp32 slabs, written here and read back by the reduce, at ~3 TB/s each way
+            slab_bytes = d.kpad_w * d.cn_pad * 4
+            t_stage = max(stage_bytes.value / 60e3, 0.25)
+            best = None
+            for s_ in range(1, max(1, min(rows // 192, 256)) + 1):
+                wgs = wps * N * s_
+                stages = max(6, math.ceil(math.ceil(rows / s_) / 32))
+                cost = math.ceil(wgs / 256.0) * (stages * t_stage + 6.0) + 2.0 * N * s_ * slab_bytes / 3e6
+                if (N * s_) % 8 != 0 and wps > 1:
+                    cost *= 1.07      # tiles of a slab spread over the XCDs: every L2 fetches its own copy of the rows
+                if best is None or cost < best[0]:
+                    best = (cost, s_)
+            return best[1]
+        nwg = ((d.kpad_w // 128) * (d.cn_pad // lib.ctseg_wgrad_tile_cols(d.Cn))) * N
+        # workgroups to aim for: 1024 with 16-bit storage (2048 measured +0.1 ms/step once the kernel's address code got cheaper:
+        # more slabs to write and reduce; 512 is +0.35); fp32 storage keeps 2048 (its trajectory test pins a summation order)
+        target = int(os.environ.get("CTSEG_WGRAD_TARGET_WGS", "1024" if nat.is16(plan.dt) else "2048"))
+        splits = max(1, min(math.ceil(target / nwg), math.ceil(rows / 512), 1024))
+        if splits >= m:
+            splits = splits // m * m
+        return splits
+
     def emit_wgrad(self, x, dy, bias_done=False, dyn=None):
         """weight + bias gradients straight into the flat gradient buffer (deterministic split-K).  ``dyn`` = (g, norm, sums): ``dy``
         holds the lower column block only; the upper one is the InstanceNorm + PReLU backward of ``g`` through ``norm``, formed on
@@ -493,16 +527,6 @@ class GemmLayer:
         rows = rowgrid[0] * rowgrid[1] * rowgrid[2]
         bnw = lib.ctseg_wgrad_tile_cols(cn)
         kpad_w, cn_pad = rup(self.T * cg + 1, 128), rup(cn, bnw)
-        nwg = (kpad_w // 128) * (cn_pad // bnw) * N
-        # workgroups to aim for: 1024 with 16-bit storage (2048 measured +0.1 ms/step once the kernel's address code got cheaper:
-        # more slabs to write and reduce; 512 is +0.35); fp32 storage keeps 2048 (its trajectory test pins a summation order)
-        target = int(os.environ.get("CTSEG_WGRAD_TARGET_WGS", "1024" if nat.is16(plan.dt) else "2048"))
-        splits = max(1, min(math.ceil(target / nwg), math.ceil(rows / 512), 1024))
-        # slabs (N * splits) in multiples of 8: the kernel then keeps all K / column blocks of a slab on one XCD (one L2 fetch
-        # of the rows they share instead of one per XCD)
-        m = 8 // math.gcd(N, 8)
-        if splits >= m:
-            splits = splits // m * m
         d = nat.WgradDesc()
         d.in_, d.dy, d.dtype = gathered.ptr(), dyy.ptr(), plan.dt
         d.N, d.Xi, d.Yi, d.Zi = gathered.dims
@@ -511,7 +535,9 @@ class GemmLayer:
         d.ntaps = self.T
         for j, (_, off) in enumerate(self.wg_taps):
             d.taps[j] = off
-        d.splits, d.kpad_w, d.cn_pad = splits, kpad_w, cn_pad
+        d.splits, d.kpad_w, d.cn_pad = 1, kpad_w, cn_pad
+        splits = self._wgrad_splits(d, N, rows, dyn is not None or getattr(gathered, "pending_norm", None) is not None)
+        d.splits = splits
         if dyn is not None:
             g_up, norm, sums = dyn
             d.dyn_col0, d.dyn_g, d.dyn_g_ld, d.dyn_y, d.dyn_y_ld = dy.C, g_up.ptr(), g_up.ld, norm.y.ptr(), norm.y.ld

@@ -508,6 +508,9 @@ bool wgrad_halo_eligible(const ctseg_wgrad_desc* d);
 int wgrad_halo_slabs(const ctseg_wgrad_desc* d);
 bool wgrad_halo_in_norm_ok(const ctseg_wgrad_desc* d);
 void launch_wgrad_halo(const ctseg_wgrad_desc* d, hipStream_t st);
+bool wgrad_ring_eligible(const ctseg_wgrad_desc* d);
+int wgrad_ring_wgs_per_slab(const ctseg_wgrad_desc* d, int32_t* stage_bytes);
+int launch_wgrad_ring(const ctseg_wgrad_desc* d, hipStream_t st);
 
 template <typename T, bool SMALLC> static void launch_wgrad(WgradKArgs& a, hipStream_t st) {
   const int bnw = ctseg_wgrad_tile_cols(a.Cn);
@@ -539,6 +542,23 @@ extern "C" int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d) {
   if (wgrad_up_eligible(d)) return wgrad_up_slabs(d);
   if (wgrad_stem_eligible(d)) return wgrad_stem_slabs(d);
   return d->N * d->splits;
+}
+
+extern "C" int ctseg_conv_wgrad_wgs_per_slab(const ctseg_wgrad_desc* d, int32_t* per_cu, int32_t* stage_bytes) {
+  if (per_cu) *per_cu = 0;
+  if (stage_bytes) *stage_bytes = 0;
+  if (!desc_ok(d)) return -1;
+  if (wgrad_halo_eligible(d) || wgrad_up_eligible(d) || wgrad_stem_eligible(d)) return 0;
+  const int SZ = d->dtype == CTSEG_F32 ? 4 : 2, EPC = 16 / SZ;
+  const bool smallc = (d->Cg % EPC) != 0 || (d->g_ld % EPC) != 0 || ((uintptr_t)d->in % 16) != 0;
+  if (!smallc && wgrad_ring_eligible(d)) {
+    if (per_cu) *per_cu = 1;
+    return wgrad_ring_wgs_per_slab(d, stage_bytes);
+  }
+  const int bnw = ctseg_wgrad_tile_cols(d->Cn);
+  if (per_cu) *per_cu = 4;
+  if (stage_bytes) *stage_bytes = 32 * (128 + bnw) * SZ;
+  return (d->kpad_w / 128) * (d->cn_pad / bnw);
 }
 
 extern "C" int ctseg_wgrad_in_norm_ok(const ctseg_wgrad_desc* d) { return (desc_ok(d) && d->dtype == CTSEG_BF16 && wgrad_halo_in_norm_ok(d)) ? 1 : 0; }
@@ -595,6 +615,12 @@ extern "C" int ctseg_conv_wgrad(const ctseg_wgrad_desc* d, void* stream) {
   }
   CTSEG_REQUIRE(d->kpad_w % 128 == 0 && d->kpad_w >= ktot + 1, "conv_wgrad: kpad_w %d (K=%d)", d->kpad_w, ktot);
   CTSEG_REQUIRE(d->cn_pad % bnw == 0 && d->cn_pad >= d->Cn, "conv_wgrad: cn_pad %d", d->cn_pad);
+  if (!smallc && wgrad_ring_eligible(d)) {
+    const int rc = launch_wgrad_ring(d, (hipStream_t)stream);
+    CTSEG_REQUIRE(rc == 0, "conv_wgrad: the ring kernel cannot take this row grid (%d)", rc);
+    CTSEG_LAUNCH_CHECK("conv_wgrad_ring");
+    return 0;
+  }
   WgradKArgs a;
   a.in = (const char*)d->in; a.dy = (const char*)d->dy; a.ws = d->ws;
   a.N = d->N; a.Xi = d->Xi; a.Yi = d->Yi; a.Zi = d->Zi; a.Xr = d->Xr; a.Yr = d->Yr; a.Zr = d->Zr;

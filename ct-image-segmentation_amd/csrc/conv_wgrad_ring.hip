@@ -1,0 +1,387 @@
+// Weight gradient of the many-channel layers as a ring-pipelined GEMM over voxels (bf16, gfx950):
+//   R[slot * Cg + a][b] = sum_rows in[row * sin + d(slot)][a] * dy[row][b]        (same contract and slab layout as conv_wgrad.hip;
+// autograd's Conv3d / ConvTranspose3d weight + bias backward in the reference's training step, capstone/volumetric/base_trainer.py:80-82).
+//
+// Why a second kernel.  tools/probes/probe_mfma_lds.hip (hand-placed registers) says what the matrix pipe of a SIMD
+// tolerates beside a v_mfma_f32_16x16x32_bf16: two ds_read_b64_tr_b16 per multiply cost NOTHING when they are interleaved with the
+// multiplies of the previous stage (two fragment register sets: 90-97 % of the MFMA rate with two waves per SIMD), 76-80 % when a stage
+// is read, waited for and multiplied in turn; up to two VALU instructions per multiply are free, four cost 40 %.  conv_wgrad_kernel
+// does neither: ~6 VALU per multiply (per-chunk coordinate carries and bounds tests, two chunks per 16 multiplies), fragments read and
+// waited for in front of their multiplies, a barrier per 16 multiplies, and hipcc puts vmcnt(0) in front of the first fragment read,
+// so its direct-to-LDS prefetch is never in flight across a stage: 30-40 % of the MFMA rate.  This kernel:
+//   * 512 threads, workgroup tile (WK*KT*16) K rows x (WC*CT*16) columns, wave tile KT x CT blocks (8 x 4 or 4 x 4): 32 or 16 multiplies
+//     per 32-voxel stage and wave;
+//   * a stage is 32 voxels; D of them live in an LDS ring (128-column panels of [32 rows][256 B], the XOR swizzle of conv_wgrad.hip,
+//     applied on the source side), stage s+D-1 is requested during step s with raw.buffer.load.lds and a counted vmcnt;
+//   * a thread stages ONE voxel row per stage (row = tid / 16 of the stage) for every panel, so the coordinate carries are per
+//     thread and stage, not per chunk, and a panel costs three compares, a select and an add: ~1 VALU per multiply;
+//   * fragments of stage s+1 are read into the other register set while stage s multiplies;
+//   * the bias row (a virtual all-ones gathered channel at K index ntaps*Cg) is a register constant multiplied by the wave that owns
+//     that K row — no LDS image, no zero page.
+// Rows past the end of a split or of the sample are zero rows of dy (its buffer range IS the split), so a workgroup runs a uniform
+// number of stages whatever its split holds.
+#include <type_traits>
+
+#include "ctseg_dev.h"
+
+namespace ctseg {
+
+struct WRingKArgs {
+  const char* in;
+  const char* dy;
+  float* ws;
+  int N, Xi, Yi, Zi, Xr, Yr, Zr;
+  int Cg, Cn, g_ld, d_ld, sin, ntaps;
+  int rows, splits, rows_per_split, nst;   // nst: stages every workgroup runs (even, >= 4)
+  int kpad_w, cn_pad, d_valid;
+  int sx, sy, sz;                          // mixed-radix decomposition of a 32-row step
+  int ktiles, ctiles;                      // workgroup -> (tile, slab): ids L, L+8, ... of a group of 8*ktiles*ctiles share a slab (one XCD)
+  int xcd;                                 // 1: that order; 0: tile = blockIdx.x, slab = blockIdx.y
+  int taps[CTSEG_MAX_TAPS];
+};
+
+typedef int32_t wr_i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t __attribute__((address_space(3)))* wr_lds_u32_ptr;
+__device__ void wr_raw_buffer_load_lds(wr_i32x4 rsrc, wr_lds_u32_ptr lds, int size, int voffset, int soffset, int offset,
+                                       int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+__device__ __forceinline__ wr_i32x4 wr_make_rsrc(const void* p, uint32_t bytes) {
+  struct __attribute__((packed)) { const void* ptr; uint32_t range; uint32_t config; } r{p, bytes, 0x00020000u};
+  wr_i32x4 v = __builtin_bit_cast(wr_i32x4, r);
+  v[0] = __builtin_amdgcn_readfirstlane(v[0]);
+  v[1] = __builtin_amdgcn_readfirstlane(v[1]);
+  v[2] = __builtin_amdgcn_readfirstlane(v[2]);
+  v[3] = __builtin_amdgcn_readfirstlane(v[3]);
+  return v;
+}
+
+// Two transposed LDS reads = one bf16 MFMA operand (rows r and r + 16 of the stage).  Inline assembly: see wring_main.
+template <int HI> __device__ __forceinline__ bf16x8 wr_tr2(uint32_t addr) {
+  u32x2 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(HI) : "memory");
+  u32x4 t = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, t);
+}
+
+template <int WK_, int WC_, int KT_, int CT_, int D_> struct WRingCfg {
+  static constexpr int WK = WK_, WC = WC_, KT = KT_, CT = CT_, D = D_;
+  static constexpr int KB = WK * KT * 16, BN = WC * CT * 16, NTHR = 512;
+  static_assert(WK * WC == 8 && KB % 128 == 0 && (BN % 128 == 0 || BN == 64), "8 waves; 128-row K panels; 128- or 64-column dy panels");
+  static constexpr int AP = KB / 128;                           // K panels of [32 rows][256 B]
+  static constexpr int DP = BN >= 128 ? BN / 128 : 1;           // dy panels
+  static constexpr int DROW = BN >= 128 ? 256 : 128;            // bytes per dy panel row
+  static constexpr int DOFF = AP * 8192, STAGE = DOFF + DP * 32 * DROW;
+  static constexpr int TOTAL = D * STAGE;
+  static_assert(TOTAL <= 160 * 1024, "LDS");
+};
+
+// ND: dy panels THIS wave stages (BN = 64: one 4 KiB panel = waves 0-3 only)
+template <typename C, int ND>
+__device__ __forceinline__ void wring_main(const WRingKArgs& P, char* smem, f32x4 (&acc)[C::KT][C::CT], int n, int sp, int kb0, int col0,
+                                           int wave, int lane, int tid) {
+  constexpr int KT = C::KT, CT = C::CT, D = C::D, AP = C::AP, STAGE = C::STAGE, DOFF = C::DOFF;
+  const int wk = wave / C::WC, wc = wave % C::WC;
+  const int r16 = lane & 15, q4 = lane >> 4;
+
+  // ---- this thread's staging position: voxel row tid / 16 of a stage, 16-byte slot tid % 16 of every panel -----------------------
+  const int srow = tid >> 4, spos = tid & 15;
+  const int gl = P.g_ld * 2;
+  const int ktot = P.ntaps * P.Cg;
+  int tapoff[AP], tdx[AP], tdy[AP], tdz[AP];
+  bool kval[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int chunk = ((((spos >> 1) ^ (srow & 7)) << 1) | (spos & 1));          // logical chunk this LDS slot holds (source-side swizzle)
+    const int kpos = kb0 + p * 128 + chunk * 8;
+    kval[p] = kpos < ktot;
+    const int slot = kval[p] ? kpos / P.Cg : 0, ci = kval[p] ? kpos - slot * P.Cg : 0;
+    int t = 0;      // (a select chain over the kernel-argument table: once per thread and panel, and the table stays in SGPRs)
+#pragma unroll
+    for (int q = 0; q < CTSEG_MAX_TAPS; ++q) t = (q == slot) ? P.taps[q] : t;
+    tdx[p] = (int)(int8_t)(t & 0xff); tdy[p] = (int)(int8_t)((t >> 8) & 0xff); tdz[p] = (int)(int8_t)((t >> 16) & 0xff);
+    tapoff[p] = ((tdx[p] * P.Yi + tdy[p]) * P.Zi + tdz[p]) * gl + ci * 2;
+    if (!kval[p]) tdx[p] = 1 << 24;        // K padding (and the bias row): never inside the volume -> zeros
+  }
+  const int mstart = sp * P.rows_per_split;
+  int mend = mstart + P.rows_per_split;
+  if (mend > P.rows) mend = P.rows;
+  // scaled coordinates (x sin, y sin, z sin) of this thread's row in stage 0 and its byte offset inside the sample
+  int cx, cy, cz, aoff;
+  {
+    const int m = mstart + srow;
+    cz = m % P.Zr; const int t = m / P.Zr;
+    cy = t % P.Yr; cx = t / P.Yr;
+    cx *= P.sin; cy *= P.sin; cz *= P.sin;
+    aoff = ((cx * P.Yi + cy) * P.Zi + cz) * gl;
+  }
+  const int zrs = P.Zr * P.sin, yrs = P.Yr * P.sin;
+  const int szs = P.sz * P.sin, sys_ = P.sy * P.sin, sxs = P.sx * P.sin;
+  const int o_step = (szs + (sys_ + sxs * P.Yi) * P.Zi) * gl;
+  const int o_cz = P.sin * gl * (P.Zi - P.Zr), o_cy = P.sin * gl * P.Zi * (P.Yi - P.Yr);
+  const char* inb = P.in + (int64_t)n * P.Xi * P.Yi * P.Zi * gl;
+  const wr_i32x4 rsA = wr_make_rsrc(inb, (uint32_t)((int64_t)P.Xi * P.Yi * P.Zi * gl));
+  const char* dstage = P.dy + ((int64_t)n * P.rows + mstart) * P.d_ld * 2;
+  const wr_i32x4 rsD = wr_make_rsrc(dstage, (uint32_t)((int64_t)(mend > mstart ? mend - mstart : 0) * P.d_ld * 2));
+  // dy: panel p, this thread's row and chunk; a column past d_valid starts (and stays) out of range
+  int doff[ND > 0 ? ND : 1];
+#pragma unroll
+  for (int p = 0; p < ND; ++p) {
+    int drow, dcol;
+    if constexpr (C::BN >= 128) {
+      drow = srow;
+      dcol = col0 + p * 128 + ((((spos >> 1) ^ (srow & 7)) << 1) | (spos & 1)) * 8;
+    } else {
+      drow = tid >> 3;                                                              // 8 slots per 128-byte row, threads 0..255
+      const int pos = tid & 7;
+      dcol = col0 + ((((pos >> 1) ^ ((drow >> 1) & 3)) << 1) | (pos & 1)) * 8;
+    }
+    doff[p] = dcol < P.d_valid ? (drow * P.d_ld + dcol) * 2 : (int)0x80000000;
+  }
+  const int d_step = 32 * P.d_ld * 2;
+
+  auto dma = [&](int sl) {
+    char* dst = smem + sl * STAGE + wave * 1024;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      // (bitwise, not short-circuit: the test must stay three compares and two scalar ANDs, no exec-masked region)
+      const bool ok = (int)((unsigned)(cx + tdx[p]) < (unsigned)P.Xi) & (int)((unsigned)(cy + tdy[p]) < (unsigned)P.Yi) &
+                      (int)((unsigned)(cz + tdz[p]) < (unsigned)P.Zi);
+      const int vo = ok ? aoff + tapoff[p] : (int)0x80000000;
+      wr_raw_buffer_load_lds(rsA, (wr_lds_u32_ptr)(dst + p * 8192), 16, vo, 0, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < ND; ++p) {
+      wr_raw_buffer_load_lds(rsD, (wr_lds_u32_ptr)(dst + DOFF + p * 8192), 16, doff[p], 0, 0, 0);
+      doff[p] += d_step;
+    }
+    // this thread's row advances by 32 (mixed radix z, y, x; no multiply)
+    cz += szs;
+    const bool carry_z = cz >= zrs;
+    cz -= carry_z ? zrs : 0;
+    cy += sys_ + (carry_z ? P.sin : 0);
+    const bool carry_y = cy >= yrs;
+    cy -= carry_y ? yrs : 0;
+    cx += sxs + (carry_y ? P.sin : 0);
+    aoff += o_step + (carry_z ? o_cz : 0) + (carry_y ? o_cy : 0);
+  };
+
+  // ---- fragment addresses: lane supplies row 4*q4 + (r16>>2) [+16], columns 4*(r16&3).. of a 16-column block ------------------------
+  const int mrow = 4 * q4 + (r16 >> 2), pc2 = (r16 & 3) * 8;
+  int fa[KT], fd[CT];     // byte offset of this wave's block i / j inside a stage (panel, swizzled 32-byte slot, lane's 8 bytes)
+#pragma unroll
+  for (int i = 0; i < KT; ++i) {
+    const int gb = wk * KT + i;
+    fa[i] = (gb >> 3) * 8192 + mrow * 256 + (((gb & 7) ^ (mrow & 7)) << 5) + pc2;
+  }
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int gb = wc * CT + j;
+    if constexpr (C::BN >= 128) fd[j] = DOFF + (gb >> 3) * 8192 + mrow * 256 + (((gb & 7) ^ (mrow & 7)) << 5) + pc2;
+    else fd[j] = DOFF + mrow * 128 + (((gb & 3) ^ ((mrow >> 1) & 3)) << 5) + pc2;
+  }
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  // hipcc waits for EVERY outstanding direct-to-LDS load (vmcnt(0)) in front of a __builtin_amdgcn_ds_read_tr16_b64 (the builtin carries
+  // no memory operand it could tell apart from the ring slots being filled), which would empty the ring every step.  The reads are
+  // therefore inline assembly: the compiler neither orders them against the loads nor waits for their data -- the step does, with one
+  // lgkmcnt(0) behind its multiplies and a scheduling barrier on either side (tests/test_isa_hazards.py checks the shape of the loop).
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  auto frags = [&](int sl, bf16x8 (&af)[KT], bf16x8 (&df)[CT]) {
+    const uint32_t base = lds0 + sl * STAGE;
+#pragma unroll
+    for (int i = 0; i < KT; ++i) af[i] = wr_tr2<16 * 256>(base + fa[i]);
+#pragma unroll
+    for (int j = 0; j < CT; ++j) df[j] = wr_tr2<16 * C::DROW>(base + fd[j]);
+  };
+
+  // ---- bias row: K index ktot lives in block bias_i of this wave (or in none) ---------------------------------------------------------
+  int bias_i = -1;
+  bf16x8 onesf;
+  {
+    const int rel = ktot - kb0 - wk * KT * 16;
+    if (rel >= 0 && rel < KT * 16) bias_i = rel >> 4;
+    const unsigned short one = (r16 == (rel & 15)) ? (unsigned short)0x3f80 : (unsigned short)0;
+    s16x8 t = {(short)one, (short)one, (short)one, (short)one, (short)one, (short)one, (short)one, (short)one};
+    onesf = __builtin_bit_cast(bf16x8, t);
+  }
+  bias_i = __builtin_amdgcn_readfirstlane(bias_i);
+
+  f32x4 accb[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mmas = [&](const bf16x8 (&af)[KT], const bf16x8 (&df)[CT]) {
+#pragma unroll
+    for (int i = 0; i < KT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], df[j], acc[i][j], 0, 0, 0);
+    if (bias_i >= 0) {
+#pragma unroll
+      for (int j = 0; j < CT; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onesf, df[j], accb[j], 0, 0, 0);
+    }
+  };
+
+  constexpr int CNT = AP + ND;      // this wave's loads per stage
+  bf16x8 a0[KT], d0[CT], a1[KT], d1[CT];
+  const int nst = P.nst;            // even, >= D + 1 (host)
+#pragma unroll
+  for (int t = 0; t < D - 1; ++t) dma(t);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * CNT) : "memory");
+  __builtin_amdgcn_s_barrier();
+  frags(0, a0, d0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto step = [&](auto dma_c, auto fr_c, int sl, bf16x8 (&xa)[KT], bf16x8 (&xd)[CT], bf16x8 (&ya)[KT], bf16x8 (&yd)[CT]) {
+    constexpr bool DMA = decltype(dma_c)::value, FR = decltype(fr_c)::value;
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * CNT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const int sl1 = sl + 1 == D ? 0 : sl + 1, slp = sl == 0 ? D - 1 : sl - 1;
+    if constexpr (FR) frags(sl1, ya, yd);
+    if constexpr (DMA) dma(slp);
+    mmas(xa, xd);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the fragments of stage s+1 (read by inline assembly: nobody else waits for them)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  int sl = 0;
+  auto next = [&]() { sl = (sl + 1 == D) ? 0 : sl + 1; };
+  static_assert(D == 4, "the drain below is written for a four-deep ring");
+  // stages 0 .. nst-1; steps 0 .. nst-D request stage s+D-1, the last D-1 steps only drain.  nst - D + 1 = nst - 3 is odd for even
+  // nst, so one step runs ahead of the two-step loop.
+  step(T_{}, T_{}, sl, a0, d0, a1, d1); next();
+  for (int s = 1; s < nst - D + 1; s += 2) {
+    step(T_{}, T_{}, sl, a1, d1, a0, d0); next();
+    step(T_{}, T_{}, sl, a0, d0, a1, d1); next();
+  }
+  step(F_{}, T_{}, sl, a1, d1, a0, d0); next();
+  step(F_{}, T_{}, sl, a0, d0, a1, d1); next();
+  step(F_{}, F_{}, sl, a1, d1, a0, d0);
+  // the gathered operand's row at K index ktot is all zeros (K padding), so the bias sums simply add onto it
+  if (bias_i >= 0) {
+#pragma unroll
+    for (int i = 0; i < KT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+        if (i == bias_i) acc[i][j] += accb[j];
+  }
+}
+
+template <typename C>
+__global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(const WRingKArgs P) {
+  constexpr int KT = C::KT, CT = C::CT;
+  __shared__ __attribute__((aligned(16))) char smem[C::TOTAL];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile, zslab;
+  if (P.xcd) {
+    const int kc = P.ktiles * P.ctiles, G = 8 * kc;
+    const int L = blockIdx.x, g = L / G, r = L - g * G;
+    zslab = g * 8 + (r & 7);
+    tile = r >> 3;
+  } else {
+    tile = blockIdx.x; zslab = blockIdx.y;
+  }
+  const int kt = tile % P.ktiles, ctile = tile / P.ktiles;
+  const int kb0 = kt * C::KB, col0 = ctile * C::BN;
+  const int n = zslab / P.splits, sp = zslab % P.splits;
+
+  f32x4 acc[KT][CT];
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if constexpr (C::BN >= 128) {
+    wring_main<C, C::DP>(P, smem, acc, n, sp, kb0, col0, wave, lane, tid);
+  } else {
+    if (wave < 4) wring_main<C, 1>(P, smem, acc, n, sp, kb0, col0, wave, lane, tid);
+    else wring_main<C, 0>(P, smem, acc, n, sp, kb0, col0, wave, lane, tid);
+  }
+
+  const int wk = wave / C::WC, wc = wave % C::WC;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  float* slab = P.ws + (int64_t)zslab * P.kpad_w * P.cn_pad;
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = kb0 + (wk * KT + i) * 16 + 4 * q4 + e;
+      if (row < P.kpad_w)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) slab[(int64_t)row * P.cn_pad + col0 + (wc * CT + j) * 16 + r16] = acc[i][j][e];
+    }
+}
+
+using WRingB = WRingCfg<4, 2, 4, 4, 4>;    // 256 x 128
+using WRingC = WRingCfg<8, 1, 4, 4, 4>;    // 512 x 64
+
+// which tile serves this descriptor: 0 none, 2 = B, 3 = C.  (1 = a 256 x 256 tile, wave tile 8 x 4: twice the flops per staged byte of B
+// -- the staging traffic is what bounds these passes -- but 128 accumulators + two sets of 12 fragments do not fit 256 registers; it needs
+// the gathered fragments in ONE set, refilled behind the multiplies that used them.  Not built.)
+static int wring_kind(const ctseg_wgrad_desc* d) {
+  const char* e = getenv("CTSEG_WGRAD_RING");          // (read per call: the A/B tools and the parity test flip it inside one process)
+  if ((e != nullptr && atoi(e) == 0) || d->dtype != CTSEG_BF16) return 0;
+  if (d->Cg % 8 != 0 || d->g_ld % 8 != 0 || d->d_ld % 8 != 0 || ((uintptr_t)d->in % 16) != 0 || ((uintptr_t)d->dy % 16) != 0) return 0;
+  if (d->Cg < 32 || d->Cn < 64 || d->ntaps > 32) return 0;
+  if (d->dyn_g != nullptr || d->in_mean_rstd != nullptr) return 0;
+  if ((int64_t)d->Xi * d->Yi * d->Zi * d->g_ld * 2 >= ((int64_t)1 << 31) - 4096) return 0;      // 32-bit buffer offsets inside a sample
+  if (d->cn_pad % 128 == 0) return 2;
+  if (d->cn_pad == 64) return 3;
+  return 0;
+}
+
+bool wgrad_ring_eligible(const ctseg_wgrad_desc* d) { return wring_kind(d) != 0; }
+
+// workgroups one slab (sample x split) takes; bytes a workgroup stages per 32 rows
+int wgrad_ring_wgs_per_slab(const ctseg_wgrad_desc* d, int32_t* stage_bytes) {
+  const int kind = wring_kind(d);
+  if (kind == 0) return 0;
+  const int KB = kind == 3 ? 512 : 256, BN = kind == 1 ? 256 : kind == 2 ? 128 : 64;
+  const int ktot = d->ntaps * d->Cg;
+  if (stage_bytes) *stage_bytes = 32 * (KB + BN) * 2;
+  return ((ktot + 1 + KB - 1) / KB) * (d->cn_pad / BN);
+}
+
+template <typename C> static void launch_wring(WRingKArgs& a, hipStream_t st) {
+  const int ktot = a.ntaps * a.Cg;
+  a.ktiles = (ktot + 1 + C::KB - 1) / C::KB;
+  a.ctiles = a.cn_pad / C::BN;
+  const int zs = a.N * a.splits, tiles = a.ktiles * a.ctiles;
+  static const bool remap = !(getenv("CTSEG_WGRAD_XCD") && atoi(getenv("CTSEG_WGRAD_XCD")) == 0);
+  a.xcd = (remap && zs % 8 == 0 && tiles > 1) ? 1 : 0;
+  const dim3 grid = a.xcd ? dim3((unsigned)(tiles * zs), 1u, 1u) : dim3((unsigned)tiles, (unsigned)zs, 1u);
+  hipLaunchKernelGGL((conv_wgrad_ring_kernel<C>), grid, dim3(512), 0, st, a);
+}
+
+int launch_wgrad_ring(const ctseg_wgrad_desc* d, hipStream_t st) {
+  const int kind = wring_kind(d);
+  WRingKArgs a;
+  a.in = (const char*)d->in; a.dy = (const char*)d->dy; a.ws = d->ws;
+  a.N = d->N; a.Xi = d->Xi; a.Yi = d->Yi; a.Zi = d->Zi; a.Xr = d->Xr; a.Yr = d->Yr; a.Zr = d->Zr;
+  a.Cg = d->Cg; a.Cn = d->Cn; a.g_ld = d->g_ld; a.d_ld = d->d_ld; a.sin = d->sin; a.ntaps = d->ntaps;
+  const int64_t rows64 = (int64_t)d->Xr * d->Yr * d->Zr;
+  if (rows64 >= (1ll << 31) - 4096) return -1;
+  a.rows = (int)rows64; a.splits = d->splits;
+  int rps = (int)((rows64 + d->splits - 1) / d->splits);
+  rps = ((rps + 31) / 32) * 32;
+  a.rows_per_split = rps;
+  if ((int64_t)(rps + 64) * d->d_ld * 2 >= ((int64_t)1 << 31)) return -2;
+  int nst = rps / 32;
+  if (nst < 6) nst = 6;
+  nst += nst & 1;
+  a.nst = nst;
+  a.kpad_w = d->kpad_w; a.cn_pad = d->cn_pad;
+  const int dv = ((d->Cn + 7) / 8) * 8;
+  a.d_valid = dv < d->d_ld ? dv : d->d_ld;
+  int step = 32;
+  a.sz = step % d->Zr; step /= d->Zr;
+  a.sy = step % d->Yr; a.sx = step / d->Yr;
+  for (int i = 0; i < CTSEG_MAX_TAPS; ++i) a.taps[i] = i < d->ntaps ? d->taps[i] : 0;
+  if (kind == 2) launch_wring<WRingB>(a, st);
+  else launch_wring<WRingC>(a, st);
+  return 0;
+}
+
+}  // namespace ctseg

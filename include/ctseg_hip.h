@@ -175,6 +175,14 @@ int ctseg_wgrad_tile_cols(int32_t Cn);
 /* slabs this descriptor makes ctseg_conv_wgrad write (N*splits, or one per persistent workgroup of the LDS-halo
  * kernel that few-channel 3x3x3 stride-1 bf16 layers take): size `ws` and call the reduce with it. `ws`/`dy`/`in` may be NULL here */
 int ctseg_conv_wgrad_slabs(const ctseg_wgrad_desc* d);
+/* Workgroups ONE slab (one sample x one row range) of this pass takes, how many of them a CU holds at a time (`per_cu`) and the
+ * operand bytes one workgroup stages per 32 rows (`stage_bytes`; either may be NULL), for the caller that picks `splits`: a
+ * split-K pass costs (rounds of 256 * per_cu workgroups) x (32-row stages per workgroup) x (time of a stage: its staging
+ * traffic at ~24 B/clk/CU) plus the fp32 slabs it writes and the reduce reads back.  0: the pass is a persistent
+ * LDS-halo kernel that sizes its own grid (splits is ignored).  `splits`, `ws`, `in`, `dy` need not be set.  (The 512-thread ring
+ * kernel of the many-channel bf16 layers holds ONE 256 x 256 / 256 x 128 / 512 x 64 tile per CU; the generic kernel four
+ * 128 x 128 ones.) */
+int ctseg_conv_wgrad_wgs_per_slab(const ctseg_wgrad_desc* d, int32_t* per_cu, int32_t* stage_bytes);
 /* 1 when this weight-gradient pass may read 12-wide bf16 rows (g_ld == 12 with Cg == 16 and / or d_ld == 12): the LDS-halo kernel */
 int ctseg_wgrad_narrow_ok(const ctseg_wgrad_desc* d);
 /* 1 when this weight-gradient pass can normalise its gathered operand on the fly (the 16 -> <= 16 channel LDS-halo kernel) */

@@ -48,6 +48,36 @@ def test_no_wide_store_hazard_in_the_shipped_library():
     assert r["hazards"] == [], "\n".join(r["hazards"])
 
 
+def test_hand_waited_lds_reads_of_the_ring_weight_gradient():
+    """conv_wgrad_ring.hip reads its MFMA fragments with inline-assembly ds_read_b64_tr_b16 (hipcc would otherwise drain the ring of
+    direct-to-LDS loads in front of every read); nobody but the kernel's own `s_waitcnt lgkmcnt(0)` stands between such a read and
+    the instruction that consumes its registers.  The scanner is checked on a planted violation, then run over the shipped code."""
+    planted = """
+0000000000001000 <_ZN5ctseg22conv_wgrad_ring_kernelI1EEv>:
+        s_waitcnt vmcnt(3)
+        s_barrier
+        ds_read_b64_tr_b16 v[10:11], v5
+        ds_read_b64_tr_b16 v[12:13], v5 offset:4096
+        buffer_load_dwordx4 v7, s[20:23], 0 offen lds
+        v_mfma_f32_16x16x32_bf16 a[0:3], v[20:23], v[24:27], a[0:3]
+        s_waitcnt lgkmcnt(0)
+        v_mfma_f32_16x16x32_bf16 a[0:3], v[10:13], v[24:27], a[0:3]
+        s_barrier
+        s_endpgm
+"""
+    ok = H.scan_untracked_lds_reads(planted)
+    assert ok["kernels"] == 1 and ok["reads"] == 2 and ok["segments"] == 1 and ok["violations"] == []
+    early = H.scan_untracked_lds_reads(planted.replace("v[20:23], v[24:27]", "v[10:13], v[24:27]"))
+    assert len(early["violations"]) == 1 and "before the lgkmcnt(0)" in early["violations"][0]
+    copied = H.scan_untracked_lds_reads(planted.replace("        s_waitcnt lgkmcnt(0)", "        v_mov_b32 v30, v11\n        s_waitcnt lgkmcnt(0)"))
+    assert len(copied["violations"]) == 1
+    drained = H.scan_untracked_lds_reads(planted.replace("        ds_read_b64_tr_b16 v[10:11], v5", "        s_waitcnt vmcnt(0)\n        ds_read_b64_tr_b16 v[10:11], v5"))
+    assert len(drained["violations"]) == 1 and "vmcnt(0)" in drained["violations"][0]
+    r = H.scan_library_untracked_lds_reads()
+    assert r["kernels"] >= 2 and r["reads"] >= 100 and r["segments"] >= 4, r
+    assert r["violations"] == [], "\n".join(r["violations"])
+
+
 # scratch bytes per lane the round-3 tree is known to carry (demangled prefix -> bytes): these may shrink, never grow
 _KNOWN_SCRATCH = {
     "void ctseg::conv_down_halo_kernel<ctseg::F16, 32, true, false, -1>": 28,

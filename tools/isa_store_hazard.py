@@ -121,6 +121,139 @@ def scan_library(lib_path=DEFAULT_LIB):
     return res
 
 
+def disassemble_with_labels(obj_bytes):
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(obj_bytes)
+        f.flush()
+        return subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", "--symbolize-operands", f.name], text=True)
+
+
+def _blocks(text, kernel_substr):
+    """{kernel symbol: [block]} with block = {"label": str | None, "ins": [(mnemonic, [operands])], "succ": [block indices]};
+    text from disassemble_with_labels() (branch targets are `<L12>:` lines / `L12` operands)"""
+    kernels, cur, sym = {}, None, None
+    for ln in text.splitlines():
+        st = ln.strip()
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", st)
+        if m:
+            name = m.group(1)
+            if re.match(r"^L\d+$", name):
+                if sym is not None:
+                    cur = {"label": name, "ins": [], "succ": []}
+                    kernels[sym].append(cur)
+                continue
+            sym = name if kernel_substr in name else None
+            if sym is not None:
+                cur = {"label": None, "ins": [], "succ": []}
+                kernels[sym] = [cur]
+            continue
+        if sym is None:
+            continue
+        st = st.split("//")[0].strip()
+        if not st or st.startswith("Disassembly") or "file format" in st:
+            continue
+        parts = st.split(None, 1)
+        mn = parts[0]
+        ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        cur["ins"].append((mn, ops))
+        if mn.startswith("s_cbranch") or mn in ("s_branch", "s_endpgm"):
+            cur = {"label": None, "ins": [], "succ": []}
+            kernels[sym].append(cur)
+    for sym, bl in kernels.items():
+        by_label = {b["label"]: i for i, b in enumerate(bl) if b["label"]}
+        for i, b in enumerate(bl):
+            last = b["ins"][-1] if b["ins"] else ("", [])
+            if last[0] != "s_endpgm" and last[0] != "s_branch" and i + 1 < len(bl):
+                b["succ"].append(i + 1)
+            if (last[0].startswith("s_cbranch") or last[0] == "s_branch") and last[1] and last[1][-1] in by_label:
+                b["succ"].append(by_label[last[1][-1]])
+    return kernels
+
+
+def _sources(mn, ops):
+    if mn.startswith("ds_write") or mn.startswith("buffer_store") or mn.startswith("global_store") or mn.startswith("v_cmp") or mn.startswith("s_"):
+        return ops
+    return ops[1:]
+
+
+def scan_untracked_lds_reads(text, kernel_substr="conv_wgrad_ring_kernel"):
+    """Kernels that read LDS through inline assembly (ds_read_b64_tr_b16 in conv_wgrad_ring.hip: the compiler neither orders those
+    reads against the direct-to-LDS loads nor waits for their data) must do by hand what the compiler does for its own loads.
+    Per kernel whose symbol contains ``kernel_substr``, over its control-flow graph (text from disassemble_with_labels()):
+      * a register written by such a read may not be READ (by a multiply, a move, anything) on any path before an `s_waitcnt`
+        with lgkmcnt(0) — forward dataflow of the set of registers with a read in flight, union over predecessors;
+      * a straight-line stretch between two barriers that holds both transposed reads and direct-to-LDS loads has no
+        `s_waitcnt vmcnt(0)` (that wait would empty the ring every step — the reason the reads are inline assembly at all).
+    -> {"kernels": n, "reads": n, "segments": n, "violations": [...]}"""
+    res = {"kernels": 0, "reads": 0, "segments": 0, "violations": []}
+    for sym, bl in _blocks(text, kernel_substr).items():
+        res["kernels"] += 1
+        entry = [set() for _ in bl]
+
+        def walk(i, report):
+            pending = set(entry[i])
+            for mn, ops in bl[i]["ins"]:
+                if mn == "s_waitcnt":
+                    if "lgkmcnt(0)" in " ".join(ops):
+                        pending = set()
+                    continue
+                for o in _sources(mn, ops):
+                    hit = _regset(o.split()[0] if o else o) & pending
+                    if hit and report:
+                        res["violations"].append(f"{sym}: `{mn} {', '.join(ops)}` reads {sorted(hit)[:2]} before the lgkmcnt(0) that covers its ds_read_b64_tr_b16")
+                if mn == "ds_read_b64_tr_b16":
+                    pending |= _regset(ops[0])
+                    if report:
+                        res["reads"] += 1
+                elif ops and not mn.startswith("ds_write") and not mn.startswith("buffer_store") and not mn.startswith("global_store"):
+                    pending -= _regset(ops[0].split()[0])          # (overwritten by something the compiler tracks)
+            return pending
+
+        changed = True
+        while changed:
+            changed = False
+            for i in range(len(bl)):
+                out = walk(i, False)
+                for j in bl[i]["succ"]:
+                    if not out <= entry[j]:
+                        entry[j] |= out
+                        changed = True
+        for i in range(len(bl)):
+            walk(i, True)
+        # ring steps: the stretch from a barrier to the next one (or to the end of its basic block: a step may end in a branch)
+        for b in bl:
+            reads = dma = drain = 0
+
+            def close():
+                if reads and dma:
+                    res["segments"] += 1
+                    if drain:
+                        res["violations"].append(f"{sym}: s_waitcnt vmcnt(0) in a ring step that both reads fragments and requests a stage")
+
+            for mn, ops in b["ins"]:
+                if mn == "s_barrier":
+                    close()
+                    reads = dma = drain = 0
+                elif mn == "s_waitcnt" and "vmcnt(0)" in " ".join(ops):
+                    drain += 1
+                elif mn == "ds_read_b64_tr_b16":
+                    reads += 1
+                elif mn.startswith("buffer_load") and any("lds" in o for o in ops):
+                    dma += 1
+            close()
+    return res
+
+
+def scan_library_untracked_lds_reads(lib_path=DEFAULT_LIB):
+    tot = {"kernels": 0, "reads": 0, "segments": 0, "violations": []}
+    for bi, obj in code_objects(lib_path):
+        r = scan_untracked_lds_reads(disassemble_with_labels(obj))
+        for k in ("kernels", "reads", "segments"):
+            tot[k] += r[k]
+        tot["violations"] += r["violations"]
+    return tot
+
+
 def kernel_resources(lib_path=DEFAULT_LIB):
     """{demangled-ish kernel symbol: {"scratch": bytes per lane, "vgpr": n, "spills": n, "lds": bytes}} from the code objects'
     AMDGPU metadata notes — DESIGN.md section 3.2f: a 112 B/lane spill was invisible in the kernel's own timing and cost +0.9 GB of
