@@ -6,7 +6,8 @@
 // the per-layer times that they stop at ~24 B/clk/CU of staging traffic whatever the tile — this measures that ceiling directly.
 // Each workgroup streams a region that its XCD keeps resident (region = blockIdx % 8, 2 MiB each: 8 XCDs x 4 MiB L2), or a 96 MiB
 // buffer that only the 256 MiB memory-side cache holds.  Wave-instruction footprint: 1 KiB contiguous (SEG = 1024) or 64-byte
-// pieces of rows 256 bytes apart (SEG = 64: the gather of a 32-channel layer).
+// pieces of rows 256 bytes apart (SEG = 64: the gather of a 32-channel layer or of a 32-wide K stage); "halves paired": two
+// consecutive loads of a wave fetch bytes 0-63 and 64-127 of the SAME 128-byte lines (does the vector cache keep the line?).
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/probe_l2_to_cu_bandwidth.hip -o /tmp/p && /tmp/p [MHz]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -25,7 +26,7 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p, uint32_t bytes) {
 }
 
 // MODE 0: global_load_dwordx4 -> VGPR; 1: dwordx4 -> LDS; 2: dword -> LDS.  INFL loads in flight per wave.
-template <int MODE, int SEG, int INFL> __global__ __launch_bounds__(512) void stream(const char* buf, uint32_t region_bytes, int regions, int iters, uint32_t* out) {
+template <int MODE, int SEG, int INFL, int PAIR = 0> __global__ __launch_bounds__(512) void stream(const char* buf, uint32_t region_bytes, int regions, int iters, uint32_t* out) {
   __shared__ __attribute__((aligned(16))) char smem[64 * 1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const char* reg = buf + (size_t)(blockIdx.x % regions) * region_bytes;
@@ -53,27 +54,27 @@ template <int MODE, int SEG, int INFL> __global__ __launch_bounds__(512) void st
     } else {
 #pragma unroll
       for (int k = 0; k < INFL; ++k) {
-        uint32_t o = pos + k * FOOT * nw;
+        uint32_t o = PAIR ? pos + (k >> 1) * FOOT * nw + (k & 1) * 64 : pos + k * FOOT * nw;     // PAIR: loads 2j, 2j+1 = the two halves of the same lines
         o = o >= region_bytes ? o - region_bytes : o;
         raw_buffer_load_lds(rs, (lds_u32_ptr)(smem + wave * (INFL * 64 * W) + k * 64 * W), W, (int)(o + loff), 0, 0, 0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    pos += INFL * FOOT * nw;
+    pos += (PAIR ? INFL / 2 : INFL) * FOOT * nw;
     pos = pos >= region_bytes ? pos - region_bytes : pos;
   }
   if constexpr (MODE != 0) { __syncthreads(); acc[0] = *reinterpret_cast<uint32_t*>(smem + tid * 4); }
   out[blockIdx.x * blockDim.x + tid] = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
 }
 
-template <int MODE, int SEG, int INFL> static void run(const char* name, const char* buf, uint32_t region, int regions, int threads, int wg_per_cu, uint32_t* out, double mhz) {
+template <int MODE, int SEG, int INFL, int PAIR = 0> static void run(const char* name, const char* buf, uint32_t region, int regions, int threads, int wg_per_cu, uint32_t* out, double mhz) {
   hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
   const int iters = 2000;
   const int W = MODE == 2 ? 4 : 16;
   float best = 1e9;
   for (int rep = 0; rep < 3; ++rep) {
     (void)hipEventRecord(a);
-    hipLaunchKernelGGL((stream<MODE, SEG, INFL>), dim3(256 * wg_per_cu), dim3(threads), 0, 0, buf, region, regions, iters, out);
+    hipLaunchKernelGGL((stream<MODE, SEG, INFL, PAIR>), dim3(256 * wg_per_cu), dim3(threads), 0, 0, buf, region, regions, iters, out);
     (void)hipEventRecord(b); (void)hipEventSynchronize(b);
     float ms; (void)hipEventElapsedTime(&ms, a, b); best = ms < best ? ms : best;
   }
@@ -95,6 +96,8 @@ int main(int argc, char** argv) {
   run<1, 1024, 8>("buffer_load_dwordx4 -> LDS, 1 KiB rows", buf, 2u << 20, 8, 512, 1, out, mhz);
   run<1, 1024, 8>("buffer_load_dwordx4 -> LDS, 1 KiB rows", buf, 2u << 20, 8, 256, 2, out, mhz);
   run<1, 64, 8>("buffer_load_dwordx4 -> LDS, 64 B pieces", buf, 2u << 20, 8, 512, 1, out, mhz);
+  run<1, 64, 8, 1>("dwordx4 -> LDS, 64 B pieces, halves paired", buf, 2u << 20, 8, 512, 1, out, mhz);
+  run<1, 64, 4, 1>("dwordx4 -> LDS, 64 B pieces, halves paired", buf, 2u << 20, 8, 512, 1, out, mhz);
   run<2, 1024, 8>("buffer_load_dword -> LDS, 256 B rows", buf, 2u << 20, 8, 512, 1, out, mhz);
   printf("memory-side cache (one 96 MiB region):\n");
   run<0, 1024, 8>("global_load_dwordx4 -> VGPR, 1 KiB rows", buf, 96u << 20, 1, 512, 1, out, mhz);
