@@ -184,87 +184,146 @@ __device__ __forceinline__ void wring_main(const WRingKArgs& P, char* smem, f32x
   // no memory operand it could tell apart from the ring slots being filled), which would empty the ring every step.  The reads are
   // therefore inline assembly: the compiler neither orders them against the loads nor waits for their data -- the step does, with one
   // lgkmcnt(0) behind its multiplies and a scheduling barrier on either side (tests/test_isa_hazards.py checks the shape of the loop).
-  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
-  auto frags = [&](int sl, bf16x8 (&af)[KT], bf16x8 (&df)[CT]) {
-    const uint32_t base = lds0 + sl * STAGE;
-#pragma unroll
-    for (int i = 0; i < KT; ++i) af[i] = wr_tr2<16 * 256>(base + fa[i]);
-#pragma unroll
-    for (int j = 0; j < CT; ++j) df[j] = wr_tr2<16 * C::DROW>(base + fd[j]);
-  };
-
-  // ---- bias row: K index ktot lives in block bias_i of this wave (or in none) ---------------------------------------------------------
+  // ---- bias row: K index ktot lives in block bias_i of this wave (or in none).  The gathered operand's row there is K padding (all
+  // zeros), so the wave that owns it ORs a constant fragment -- 1.0 in that row, every voxel -- into the fragment it has just read.
   int bias_i = -1;
-  bf16x8 onesf;
+  uint32_t one2;       // two bf16 1.0 in the lanes that hold row (ktot - kb0) % 16 of a block, 0 elsewhere
   {
     const int rel = ktot - kb0 - wk * KT * 16;
     if (rel >= 0 && rel < KT * 16) bias_i = rel >> 4;
-    const unsigned short one = (r16 == (rel & 15)) ? (unsigned short)0x3f80 : (unsigned short)0;
-    s16x8 t = {(short)one, (short)one, (short)one, (short)one, (short)one, (short)one, (short)one, (short)one};
-    onesf = __builtin_bit_cast(bf16x8, t);
+    one2 = (r16 == (rel & 15)) ? 0x3f803f80u : 0u;
   }
   bias_i = __builtin_amdgcn_readfirstlane(bias_i);
-
-  f32x4 accb[CT];
-#pragma unroll
-  for (int j = 0; j < CT; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mmas = [&](const bf16x8 (&af)[KT], const bf16x8 (&df)[CT]) {
-#pragma unroll
-    for (int i = 0; i < KT; ++i)
-#pragma unroll
-      for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], df[j], acc[i][j], 0, 0, 0);
+  auto add_bias = [&](bf16x8 (&af)[KT], int i0, int i1) {       // blocks i0 .. i1-1 of `af` have landed
     if (bias_i >= 0) {
 #pragma unroll
-      for (int j = 0; j < CT; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onesf, df[j], accb[j], 0, 0, 0);
+      for (int i = 0; i < KT; ++i)
+        if (i >= i0 && i < i1 && i == bias_i) {
+          u32x4 t = __builtin_bit_cast(u32x4, af[i]);
+          t[0] |= one2; t[1] |= one2; t[2] |= one2; t[3] |= one2;
+          af[i] = __builtin_bit_cast(bf16x8, t);
+        }
     }
   };
 
   constexpr int CNT = AP + ND;      // this wave's loads per stage
-  bf16x8 a0[KT], d0[CT], a1[KT], d1[CT];
-  const int nst = P.nst;            // even, >= D + 1 (host)
-#pragma unroll
-  for (int t = 0; t < D - 1; ++t) dma(t);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * CNT) : "memory");
-  __builtin_amdgcn_s_barrier();
-  frags(0, a0, d0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-
-  auto step = [&](auto dma_c, auto fr_c, int sl, bf16x8 (&xa)[KT], bf16x8 (&xd)[CT], bf16x8 (&ya)[KT], bf16x8 (&yd)[CT]) {
-    constexpr bool DMA = decltype(dma_c)::value, FR = decltype(fr_c)::value;
-    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * CNT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    const int sl1 = sl + 1 == D ? 0 : sl + 1, slp = sl == 0 ? D - 1 : sl - 1;
-    if constexpr (FR) frags(sl1, ya, yd);
-    if constexpr (DMA) dma(slp);
-    mmas(xa, xd);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the fragments of stage s+1 (read by inline assembly: nobody else waits for them)
-    __builtin_amdgcn_sched_barrier(0);
-  };
+  const int nst = P.nst;            // even, >= D + 2 (host)
   using T_ = std::true_type;
   using F_ = std::false_type;
-  int sl = 0;
-  auto next = [&]() { sl = (sl + 1 == D) ? 0 : sl + 1; };
-  static_assert(D == 4, "the drain below is written for a four-deep ring");
-  // stages 0 .. nst-1; steps 0 .. nst-D request stage s+D-1, the last D-1 steps only drain.  nst - D + 1 = nst - 3 is odd for even
-  // nst, so one step runs ahead of the two-step loop.
-  step(T_{}, T_{}, sl, a0, d0, a1, d1); next();
-  for (int s = 1; s < nst - D + 1; s += 2) {
-    step(T_{}, T_{}, sl, a1, d1, a0, d0); next();
+  static_assert(D == 4, "the drains below are written for a four-deep ring");
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+
+  if constexpr (KT == 8) {
+    // 8 x 4 wave tile: 128 accumulators leave room for ONE set of gathered fragments (8) beside two sets of dy fragments (2 x 4).
+    // The gathered set is refilled in halves behind the multiplies that used it: while blocks 0-3 of stage s multiply, blocks 4-7 of
+    // stage s are read; while blocks 4-7 multiply, blocks 0-3 and the dy fragments of stage s+1 are read.
+    bf16x8 af[KT], d0[CT], d1[CT];
+    auto rd_a = [&](int sl, int i0, int i1) {
+      const uint32_t base = lds0 + sl * STAGE;
+#pragma unroll
+      for (int i = 0; i < KT; ++i)
+        if (i >= i0 && i < i1) af[i] = wr_tr2<16 * 256>(base + fa[i]);
+    };
+    auto rd_d = [&](int sl, bf16x8 (&df)[CT]) {
+      const uint32_t base = lds0 + sl * STAGE;
+#pragma unroll
+      for (int j = 0; j < CT; ++j) df[j] = wr_tr2<16 * C::DROW>(base + fd[j]);
+    };
+    auto mm = [&](int i0, int i1, const bf16x8 (&df)[CT]) {
+#pragma unroll
+      for (int i = 0; i < KT; ++i)
+        if (i >= i0 && i < i1)
+#pragma unroll
+          for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], df[j], acc[i][j], 0, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < D - 1; ++t) dma(t);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * CNT) : "memory");
+    __builtin_amdgcn_s_barrier();
+    rd_a(0, 0, 4);
+    rd_d(0, d0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    add_bias(af, 0, 4);
+    auto step = [&](auto dma_c, auto fr_c, int sl, bf16x8 (&xd)[CT], bf16x8 (&yd)[CT]) {
+      constexpr bool DMA = decltype(dma_c)::value, FR = decltype(fr_c)::value;
+      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * CNT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const int sl1 = sl + 1 == D ? 0 : sl + 1, slp = sl == 0 ? D - 1 : sl - 1;
+      rd_a(sl, 4, 8);                         // the other half of THIS stage (its slot is not requested into before step s+1)
+      if constexpr (DMA) dma(slp);
+      mm(0, 4, xd);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      add_bias(af, 4, 8);
+      if constexpr (FR) { rd_a(sl1, 0, 4); rd_d(sl1, yd); }
+      mm(4, 8, xd);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (FR) add_bias(af, 0, 4);
+    };
+    int sl = 0;
+    auto next = [&]() { sl = (sl + 1 == D) ? 0 : sl + 1; };
+    step(T_{}, T_{}, sl, d0, d1); next();
+    for (int s = 1; s < nst - D + 1; s += 2) {
+      step(T_{}, T_{}, sl, d1, d0); next();
+      step(T_{}, T_{}, sl, d0, d1); next();
+    }
+    step(F_{}, T_{}, sl, d1, d0); next();
+    step(F_{}, T_{}, sl, d0, d1); next();
+    step(F_{}, F_{}, sl, d1, d0);
+  } else {
+    bf16x8 a0[KT], d0[CT], a1[KT], d1[CT];
+    auto frags = [&](int sl, bf16x8 (&af)[KT], bf16x8 (&df)[CT]) {
+      const uint32_t base = lds0 + sl * STAGE;
+#pragma unroll
+      for (int i = 0; i < KT; ++i) af[i] = wr_tr2<16 * 256>(base + fa[i]);
+#pragma unroll
+      for (int j = 0; j < CT; ++j) df[j] = wr_tr2<16 * C::DROW>(base + fd[j]);
+    };
+    auto mmas = [&](const bf16x8 (&af)[KT], const bf16x8 (&df)[CT]) {
+#pragma unroll
+      for (int i = 0; i < KT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], df[j], acc[i][j], 0, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < D - 1; ++t) dma(t);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * CNT) : "memory");
+    __builtin_amdgcn_s_barrier();
+    frags(0, a0, d0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    add_bias(a0, 0, KT);
+
+    auto step = [&](auto dma_c, auto fr_c, int sl, bf16x8 (&xa)[KT], bf16x8 (&xd)[CT], bf16x8 (&ya)[KT], bf16x8 (&yd)[CT]) {
+      constexpr bool DMA = decltype(dma_c)::value, FR = decltype(fr_c)::value;
+      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * CNT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const int sl1 = sl + 1 == D ? 0 : sl + 1, slp = sl == 0 ? D - 1 : sl - 1;
+      if constexpr (FR) frags(sl1, ya, yd);
+      if constexpr (DMA) dma(slp);
+      mmas(xa, xd);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the fragments of stage s+1 (read by inline assembly: nobody else waits for them)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (FR) add_bias(ya, 0, KT);
+    };
+    int sl = 0;
+    auto next = [&]() { sl = (sl + 1 == D) ? 0 : sl + 1; };
+    // stages 0 .. nst-1; steps 0 .. nst-D request stage s+D-1, the last D-1 steps only drain.  nst - D + 1 = nst - 3 is odd for even
+    // nst, so one step runs ahead of the two-step loop.
     step(T_{}, T_{}, sl, a0, d0, a1, d1); next();
-  }
-  step(F_{}, T_{}, sl, a1, d1, a0, d0); next();
-  step(F_{}, T_{}, sl, a0, d0, a1, d1); next();
-  step(F_{}, F_{}, sl, a1, d1, a0, d0);
-  // the gathered operand's row at K index ktot is all zeros (K padding), so the bias sums simply add onto it
-  if (bias_i >= 0) {
-#pragma unroll
-    for (int i = 0; i < KT; ++i)
-#pragma unroll
-      for (int j = 0; j < CT; ++j)
-        if (i == bias_i) acc[i][j] += accb[j];
+    for (int s = 1; s < nst - D + 1; s += 2) {
+      step(T_{}, T_{}, sl, a1, d1, a0, d0); next();
+      step(T_{}, T_{}, sl, a0, d0, a1, d1); next();
+    }
+    step(F_{}, T_{}, sl, a1, d1, a0, d0); next();
+    step(F_{}, T_{}, sl, a0, d0, a1, d1); next();
+    step(F_{}, F_{}, sl, a1, d1, a0, d0);
   }
 }
 
@@ -314,12 +373,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(const WRingKArgs P
     }
 }
 
+using WRingA = WRingCfg<2, 4, 8, 4, 4>;    // 256 K rows x 256 columns
 using WRingB = WRingCfg<4, 2, 4, 4, 4>;    // 256 x 128
 using WRingC = WRingCfg<8, 1, 4, 4, 4>;    // 512 x 64
 
-// which tile serves this descriptor: 0 none, 2 = B, 3 = C.  (1 = a 256 x 256 tile, wave tile 8 x 4: twice the flops per staged byte of B
-// -- the staging traffic is what bounds these passes -- but 128 accumulators + two sets of 12 fragments do not fit 256 registers; it needs
-// the gathered fragments in ONE set, refilled behind the multiplies that used them.  Not built.)
+// which tile serves this descriptor: 0 none, 1 = A, 2 = B, 3 = C
 static int wring_kind(const ctseg_wgrad_desc* d) {
   const char* e = getenv("CTSEG_WGRAD_RING");          // (read per call: the A/B tools and the parity test flip it inside one process)
   if ((e != nullptr && atoi(e) == 0) || d->dtype != CTSEG_BF16) return 0;
@@ -327,6 +385,8 @@ static int wring_kind(const ctseg_wgrad_desc* d) {
   if (d->Cg < 32 || d->Cn < 64 || d->ntaps > 32) return 0;
   if (d->dyn_g != nullptr || d->in_mean_rstd != nullptr) return 0;
   if ((int64_t)d->Xi * d->Yi * d->Zi * d->g_ld * 2 >= ((int64_t)1 << 31) - 4096) return 0;      // 32-bit buffer offsets inside a sample
+  const char* ea = getenv("CTSEG_WGRAD_RING_A");       // (A/B: 0 keeps the 256 x 128 tile for the 256-column layers)
+  if (d->cn_pad % 256 == 0 && !(ea != nullptr && atoi(ea) == 0)) return 1;
   if (d->cn_pad % 128 == 0) return 2;
   if (d->cn_pad == 64) return 3;
   return 0;
@@ -379,7 +439,8 @@ int launch_wgrad_ring(const ctseg_wgrad_desc* d, hipStream_t st) {
   a.sz = step % d->Zr; step /= d->Zr;
   a.sy = step % d->Yr; a.sx = step / d->Yr;
   for (int i = 0; i < CTSEG_MAX_TAPS; ++i) a.taps[i] = i < d->ntaps ? d->taps[i] : 0;
-  if (kind == 2) launch_wring<WRingB>(a, st);
+  if (kind == 1) launch_wring<WRingA>(a, st);
+  else if (kind == 2) launch_wring<WRingB>(a, st);
   else launch_wring<WRingC>(a, st);
   return 0;
 }

@@ -27,7 +27,9 @@ CASES = [
     ("64->64 s1 (512x64 tile), ragged rows", lambda: torch.nn.Conv3d(64, 64, 3, 1, 1), (2, 7, 10, 6)),
     ("32->128 s2 (256x128 tile, K = 865 of 1024)", lambda: torch.nn.Conv3d(32, 128, 3, 2, 1), (2, 12, 16, 8)),
     ("128->128 s1 (bias row in a tile of its own: K = 3456 = 13.5 x 256)", lambda: torch.nn.Conv3d(128, 128, 3, 1, 1), (1, 6, 8, 6)),
-    ("64->256 s1 (two column tiles)", lambda: torch.nn.Conv3d(64, 256, 3, 1, 1), (2, 6, 6, 6)),
+    ("64->256 s1 (256x256 tile)", lambda: torch.nn.Conv3d(64, 256, 3, 1, 1), (2, 6, 6, 6)),
+    ("256->256 s1 (256x256 tile; K = 6912 = 27 x 256: bias-only last tile)", lambda: torch.nn.Conv3d(256, 256, 3, 1, 1), (1, 4, 6, 6)),
+    ("128->256 s1 (256x256 tile, bias row inside the last tile), two samples", lambda: torch.nn.Conv3d(128, 256, 3, 1, 1), (2, 5, 6, 7)),
     ("64->384 s2 (three column tiles)", lambda: torch.nn.Conv3d(64, 384, 3, 2, 1), (1, 8, 8, 12)),
     ("transposed 128->32 s2 (roles swapped: gathered = dOut)", lambda: torch.nn.ConvTranspose3d(128, 32, 3, 2, 1, output_padding=1), (2, 6, 6, 4)),
     ("transposed 256->64 s2", lambda: torch.nn.ConvTranspose3d(256, 64, 3, 2, 1, output_padding=1), (1, 4, 6, 6)),
