@@ -86,3 +86,53 @@ def test_pack_block_structs_mirror_the_header():
         assert names == [f[0] for f in cls._fields_], (cname, names)
     assert ctypes.sizeof(nat.PackPart) == 32 and ctypes.sizeof(nat.PackBlock) == 8 + 4 * 4 + 8 + 2 * 32 + 4 * nat.MAX_TAPS + 4
     assert int(re.search(r"#define CTSEG_PACK_LDS_FLOATS (\d+)", open(HEADER).read()).group(1)) == nat.PACK_LDS_FLOATS
+
+
+def test_weight_gradient_sizing_query_and_the_split_model():
+    """ctseg_conv_wgrad_wgs_per_slab (host-side, no GPU): which kernel a descriptor gets and what one slab of it costs; and the split
+    count capstone_amd.engine.GemmLayer._wgrad_splits derives from it for the many-channel layers of the reference's network
+    (UNet(3,1,10,(32,64,128,256),(2,2,2,2),2) on 2x1x512x512x48, /root/reference/capstone/volumetric/base_trainer.py:65-72)."""
+    import types
+    from capstone_amd.engine import GemmLayer
+    L = nat.lib()
+
+    def desc(cg, cn, rows, sin=1, dt=nat.BF16, taps=27, N=2):
+        d = nat.WgradDesc()
+        d.dtype = dt
+        d.in_, d.dy = 4096, 8192                       # (only their alignment is looked at)
+        d.N = N
+        d.Xr, d.Yr, d.Zr = rows
+        d.Xi, d.Yi, d.Zi = [r * sin for r in rows]
+        d.Cg, d.Cn, d.g_ld, d.d_ld, d.sin, d.ntaps = cg, cn, cg, cn, sin, taps
+        bnw = L.ctseg_wgrad_tile_cols(cn)
+        d.splits, d.kpad_w, d.cn_pad = 1, -(-(taps * cg + 1) // 128) * 128, -(-cn // bnw) * bnw
+        return d
+
+    def ask(d):
+        pc, sb = ctypes.c_int32(-1), ctypes.c_int32(-1)
+        return L.ctseg_conv_wgrad_wgs_per_slab(ctypes.byref(d), ctypes.byref(pc), ctypes.byref(sb)), pc.value, sb.value
+
+    # ring kernel: 256 x 256 tile (cn_pad % 256 == 0), 256 x 128, 512 x 64; one workgroup per CU; bytes of a 32-row stage
+    assert ask(desc(256, 256, (64, 64, 6))) == (28, 1, 32 * 512 * 2)          # 27 K tiles + the bias row's own
+    assert ask(desc(128, 128, (64, 64, 6))) == (14, 1, 32 * 384 * 2)
+    assert ask(desc(64, 384, (64, 64, 6), sin=2)) == (7 * 3, 1, 32 * 384 * 2)
+    assert ask(desc(64, 64, (128, 128, 12))) == (4, 1, 32 * 576 * 2)
+    # fp32 storage and the few-channel layers keep the generic kernel (four 128-row tiles per CU) ...
+    assert ask(desc(64, 64, (128, 128, 12), dt=nat.F32)) == (14, 4, 32 * (128 + 64) * 4)
+    assert ask(desc(48, 40, (40, 40, 20)))[1] == 4
+    # ... persistent LDS-halo kernels size their own grid
+    assert ask(desc(32, 32, (256, 256, 24))) == (0, 0, 0)
+    z = nat.WgradDesc()
+    z.struct_size = 8
+    assert L.ctseg_conv_wgrad_wgs_per_slab(ctypes.byref(z), None, None) < 0
+
+    stub = types.SimpleNamespace(plan=types.SimpleNamespace(dt=nat.BF16))
+    for cg, cn, rows, sin in ((256, 256, (64, 64, 6), 1), (128, 256, (64, 64, 6), 1), (64, 64, (128, 128, 12), 1), (32, 128, (128, 128, 12), 2)):
+        d = desc(cg, cn, rows, sin)
+        s = GemmLayer._wgrad_splits(stub, d, 2, rows[0] * rows[1] * rows[2], False)
+        wps = ask(d)[0]
+        assert 1 <= s and rows[0] * rows[1] * rows[2] // s >= 192, (cg, cn, s)
+        assert 192 <= wps * 2 * s <= 256, (cg, cn, s, wps * 2 * s)           # one nearly full round of 256 workgroups
+    # the generic rule is untouched (fp32 storage: 2048 workgroups aimed for, slabs in multiples of 8)
+    stub32 = types.SimpleNamespace(plan=types.SimpleNamespace(dt=nat.F32))
+    assert GemmLayer._wgrad_splits(stub32, desc(64, 64, (128, 128, 12), dt=nat.F32), 2, 128 * 128 * 12, False) == 72
