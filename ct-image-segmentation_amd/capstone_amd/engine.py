@@ -488,7 +488,7 @@ class GemmLayer:
             best = None
             for s_ in range(1, max(1, min(rows // 192, 256)) + 1):
                 wgs = wps * N * s_
-                stages = max(6, math.ceil(math.ceil(rows / s_) / 32))
+                stages = max(8, math.ceil(math.ceil(rows / s_) / 32))
                 cost = math.ceil(wgs / 256.0) * (stages * t_stage + 6.0) + 2.0 * N * s_ * slab_bytes / 3e6
                 if (N * s_) % 8 != 0 and wps > 1:
                     cost *= 1.07      # tiles of a slab spread over the XCDs: every L2 fetches its own copy of the rows

@@ -201,7 +201,7 @@ def scan_untracked_lds_reads(text, kernel_substr="conv_wgrad_ring_kernel"):
                     hit = _regset(o.split()[0] if o else o) & pending
                     if hit and report:
                         res["violations"].append(f"{sym}: `{mn} {', '.join(ops)}` reads {sorted(hit)[:2]} before the lgkmcnt(0) that covers its ds_read_b64_tr_b16")
-                if mn == "ds_read_b64_tr_b16":
+                if mn in ("ds_read_b64_tr_b16", "ds_read_b64"):          # (every LDS read of these kernels is inline assembly)
                     pending |= _regset(ops[0])
                     if report:
                         res["reads"] += 1
