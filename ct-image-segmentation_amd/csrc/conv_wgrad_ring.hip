@@ -2,22 +2,21 @@
 //   R[slot * Cg + a][b] = sum_rows in[row * sin + d(slot)][a] * dy[row][b]        (same contract and slab layout as conv_wgrad.hip;
 // autograd's Conv3d / ConvTranspose3d weight + bias backward in the reference's training step, capstone/volumetric/base_trainer.py:80-82).
 //
-// Why a second kernel.  tools/probes/probe_mfma_lds.hip (hand-placed registers) says what the matrix pipe of a SIMD
-// tolerates beside a v_mfma_f32_16x16x32_bf16: two ds_read_b64_tr_b16 per multiply cost NOTHING when they are interleaved with the
-// multiplies of the previous stage (two fragment register sets: 90-97 % of the MFMA rate with two waves per SIMD), 76-80 % when a stage
-// is read, waited for and multiplied in turn; up to two VALU instructions per multiply are free, four cost 40 %.  conv_wgrad_kernel
-// does neither: ~6 VALU per multiply (per-chunk coordinate carries and bounds tests, two chunks per 16 multiplies), fragments read and
-// waited for in front of their multiplies, a barrier per 16 multiplies, and hipcc puts vmcnt(0) in front of the first fragment read,
-// so its direct-to-LDS prefetch is never in flight across a stage: 30-40 % of the MFMA rate.  This kernel:
-//   * 512 threads, workgroup tile (WK*KT*16) K rows x (WC*CT*16) columns, wave tile KT x CT blocks (8 x 4 or 4 x 4): 32 or 16 multiplies
-//     per 32-voxel stage and wave;
-//   * a stage is 32 voxels; D of them live in an LDS ring (128-column panels of [32 rows][256 B], the XOR swizzle of conv_wgrad.hip,
-//     applied on the source side), stage s+D-1 is requested during step s with raw.buffer.load.lds and a counted vmcnt;
-//   * a thread stages ONE voxel row per stage (row = tid / 16 of the stage) for every panel, so the coordinate carries are per
-//     thread and stage, not per chunk, and a panel costs three compares, a select and an add: ~1 VALU per multiply;
-//   * fragments of stage s+1 are read into the other register set while stage s multiplies;
-//   * the bias row (a virtual all-ones gathered channel at K index ntaps*Cg) is a register constant multiplied by the wave that owns
-//     that K row — no LDS image, no zero page.
+// Why a second kernel (measurements: DESIGN.md 3.2k).  These GEMMs are bound by the bytes a workgroup stages from L2 per flop
+// (tools/probes/probe_l2_to_cu_bandwidth.hip: a CU pulls ~50 B/clk of contiguous, ~30 B/clk of 64-byte pieces), so the tile is
+// 256 x 256 / 256 x 128 / 512 x 64 instead of conv_wgrad_kernel's 128 x 128; and tools/probes/probe_mfma_lds.hip says what the matrix
+// pipe tolerates beside a v_mfma_f32_16x16x32_bf16: two ds_read_b64_tr_b16 per multiply cost nothing when they are software-pipelined
+// (90-97 % of the MFMA rate with two waves per SIMD against 76-80 % when a stage is read, waited for and multiplied in turn), up to
+// two VALU instructions per multiply are free, four cost 40 %.  conv_wgrad_kernel runs ~6 VALU per multiply, reads and waits in front
+// of its multiplies, and hipcc drains its direct-to-LDS prefetch (vmcnt(0)) in front of the first fragment read.  This kernel:
+//   * 512 threads, ONE workgroup per CU, wave tile KT x CT blocks of 16 x 16 (8 x 4 or 4 x 4): 32 or 16 multiplies per 32-voxel stage;
+//   * a stage is 32 voxels of both operands in 128-column panels of [32 rows][256 B] (conv_wgrad.hip's XOR swizzle, applied on the
+//     source side); four stages live in an LDS ring, stage s+3 is requested during step s (raw.buffer.load.lds, counted vmcnt);
+//   * per-row addressing comes from a table in LDS (byte offset + 27-neighbour mask of 512 rows at a time): a request costs an add, a
+//     bit-field extract and an OR instead of a chain of coordinate carries and bounds tests;
+//   * fragments of stage s+1 are read while stage s multiplies (two register sets; the 8 x 4 tile refills one gathered set in halves);
+//     the reads are inline assembly, waited for by the step itself (see wr_tr2);
+//   * the bias row (a virtual all-ones gathered channel at K index ntaps*Cg) is a fragment constant ORed into the K-padding row.
 // Rows past the end of a split or of the sample are zero rows of dy (its buffer range IS the split), so a workgroup runs a uniform
 // number of stages whatever its split holds.
 #include <type_traits>
@@ -58,7 +57,12 @@ __device__ __forceinline__ wr_i32x4 wr_make_rsrc(const void* p, uint32_t bytes) 
   return v;
 }
 
-// Two transposed LDS reads = one bf16 MFMA operand (rows r and r + 16 of the stage).  Inline assembly: see wring_main.
+// Two transposed LDS reads = one bf16 MFMA operand (rows r and r + 16 of the stage).
+// hipcc waits for EVERY outstanding direct-to-LDS load (vmcnt(0)) in front of a __builtin_amdgcn_ds_read_tr16_b64 (the builtin carries
+// no memory operand it could tell apart from the ring slots being filled), which would empty the ring every step.  The reads are
+// therefore inline assembly: the compiler neither orders them against the loads nor waits for their data -- the step does, with
+// lgkmcnt(0) behind its multiplies and a scheduling barrier on either side.  tests/test_isa_hazards.py disassembles the shipped
+// library and checks, over each kernel's control-flow graph, that no register such a read writes is consumed before that wait.
 template <int HI> __device__ __forceinline__ bf16x8 wr_tr2(uint32_t addr) {
   u32x2 lo, hi;
   if constexpr ((WR_ABL & 2) != 0) {
@@ -81,7 +85,7 @@ template <int WK_, int WC_, int KT_, int CT_, int D_> struct WRingCfg {
   static constexpr int DOFF = AP * 8192, STAGE = DOFF + DP * 32 * DROW;
   static constexpr int RING = D * STAGE;
   static constexpr int TAB = 2 * 512 * 8;                       // row table: two chunks of 512 rows x {byte offset, out-of-volume mask}
-  static constexpr int TOTAL = RING + TAB + 32 * 4;             // ... + the tap list
+  static constexpr int TOTAL = RING + TAB;
   static_assert(TOTAL <= 160 * 1024, "LDS");
 };
 
@@ -212,11 +216,6 @@ __device__ __forceinline__ void wring_main(const WRingKArgs& P, char* smem, f32x
     if constexpr (C::BN >= 128) fd[j] = DOFF + (gb >> 3) * 8192 + mrow * 256 + (((gb & 7) ^ (mrow & 7)) << 5) + pc2;
     else fd[j] = DOFF + mrow * 128 + (((gb & 3) ^ ((mrow >> 1) & 3)) << 5) + pc2;
   }
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  // hipcc waits for EVERY outstanding direct-to-LDS load (vmcnt(0)) in front of a __builtin_amdgcn_ds_read_tr16_b64 (the builtin carries
-  // no memory operand it could tell apart from the ring slots being filled), which would empty the ring every step.  The reads are
-  // therefore inline assembly: the compiler neither orders them against the loads nor waits for their data -- the step does, with one
-  // lgkmcnt(0) behind its multiplies and a scheduling barrier on either side (tests/test_isa_hazards.py checks the shape of the loop).
   // ---- bias row: K index ktot lives in block bias_i of this wave (or in none).  The gathered operand's row there is K padding (all
   // zeros), so the wave that owns it ORs a constant fragment -- 1.0 in that row, every voxel -- into the fragment it has just read.
   int bias_i = -1;
