@@ -67,6 +67,55 @@ template <int MODE, int SEG, int INFL, int PAIR = 0> __global__ __launch_bounds_
   out[blockIdx.x * blockDim.x + tid] = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
 }
 
+// Ring-shaped variant (what conv_igemm_ring / conv_wgrad_ring do): 512 threads, a ring of D slots of STAGE bytes in LDS; per step every
+// wave waits until all but its loads of the last D-2 steps have landed, the workgroup meets at a barrier (BAR = 1), and every wave
+// requests its share of the stage D-1 steps ahead (STAGE / 8 waves / 1 KiB direct-to-LDS loads).  Contiguous 1 KiB footprints.
+template <int STAGE, int D, int BAR> __global__ __launch_bounds__(512) void ring(const char* buf, uint32_t region_bytes, int regions, int steps, uint32_t* out) {
+  __shared__ __attribute__((aligned(16))) char smem[D * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int CNT = STAGE / 8 / 1024;                      // loads per wave and stage
+  const char* reg = buf + (size_t)(blockIdx.x % regions) * region_bytes;
+  const i32x4 rs = make_rsrc(reg, region_bytes);
+  uint32_t pos = ((blockIdx.x / regions) * 8 + wave) * 1024u * 7u % region_bytes;
+  auto request = [&](int slot) {
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+      uint32_t o = pos + k * 8192;
+      o = o >= region_bytes ? o - region_bytes : o;
+      raw_buffer_load_lds(rs, (lds_u32_ptr)(smem + slot * STAGE + (wave * CNT + k) * 1024), 16, (int)(o + lane * 16), 0, 0, 0);
+    }
+    pos += CNT * 8192;
+    pos = pos >= region_bytes ? pos - region_bytes : pos;
+  };
+#pragma unroll
+  for (int t = 0; t < D - 1; ++t) request(t);
+  int sl = D - 1;
+  for (int s = 0; s < steps; ++s) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * CNT) : "memory");
+    if (BAR) __builtin_amdgcn_s_barrier();
+    request(sl);
+    sl = sl + 1 == D ? 0 : sl + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  out[blockIdx.x * blockDim.x + tid] = *reinterpret_cast<uint32_t*>(smem + tid * 4);
+}
+
+template <int STAGE, int D, int BAR> static void run_ring(const char* name, const char* buf, uint32_t region, int regions, uint32_t* out, double mhz) {
+  hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  const int steps = 2000;
+  float best = 1e9;
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipEventRecord(a);
+    hipLaunchKernelGGL((ring<STAGE, D, BAR>), dim3(256), dim3(512), 0, 0, buf, region, regions, steps, out);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b); best = ms < best ? ms : best;
+  }
+  const double bytes = (double)256 * STAGE * steps;
+  printf("%-44s stage %2d KiB x %d slots, barrier %d: %7.2f TB/s  %6.1f B/clk/CU  (%.0f clk per step)\n", name, STAGE / 1024, D, BAR, bytes / best * 1e-9,
+         bytes / 256 / (best * 1e-3 * mhz * 1e6), best * 1e-3 * mhz * 1e6 / steps);
+}
+
 template <int MODE, int SEG, int INFL, int PAIR = 0> static void run(const char* name, const char* buf, uint32_t region, int regions, int threads, int wg_per_cu, uint32_t* out, double mhz) {
   hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
   const int iters = 2000;
@@ -99,6 +148,14 @@ int main(int argc, char** argv) {
   run<1, 64, 8, 1>("dwordx4 -> LDS, 64 B pieces, halves paired", buf, 2u << 20, 8, 512, 1, out, mhz);
   run<1, 64, 4, 1>("dwordx4 -> LDS, 64 B pieces, halves paired", buf, 2u << 20, 8, 512, 1, out, mhz);
   run<2, 1024, 8>("buffer_load_dword -> LDS, 256 B rows", buf, 2u << 20, 8, 512, 1, out, mhz);
+  printf("ring-shaped staging, L2-resident (the structure of conv_igemm_ring / conv_wgrad_ring, loads only):\n");
+  run_ring<32768, 4, 1>("ring, 1 KiB rows", buf, 2u << 20, 8, out, mhz);
+  run_ring<32768, 4, 0>("ring, 1 KiB rows", buf, 2u << 20, 8, out, mhz);
+  run_ring<24576, 5, 1>("ring, 1 KiB rows", buf, 2u << 20, 8, out, mhz);
+  run_ring<24576, 6, 1>("ring, 1 KiB rows", buf, 2u << 20, 8, out, mhz);
+  run_ring<16384, 8, 1>("ring, 1 KiB rows", buf, 2u << 20, 8, out, mhz);
+  run_ring<8192, 16, 1>("ring, 1 KiB rows", buf, 2u << 20, 8, out, mhz);
+  run_ring<32768, 4, 1>("ring, 1 KiB rows, one 24 MiB region", buf, 24u << 20, 1, out, mhz);
   printf("memory-side cache (one 96 MiB region):\n");
   run<0, 1024, 8>("global_load_dwordx4 -> VGPR, 1 KiB rows", buf, 96u << 20, 1, 512, 1, out, mhz);
   run<1, 1024, 8>("buffer_load_dwordx4 -> LDS, 1 KiB rows", buf, 96u << 20, 1, 512, 1, out, mhz);
